@@ -1,0 +1,68 @@
+// Internal helpers shared by every translation unit of libsrganst.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+
+#define SST_API extern "C" __attribute__((visibility("default")))
+
+// ---- error convention: every entry returns int, 0 = ok, message via sst_last_error()
+enum : int {
+  SST_OK = 0,
+  SST_ERR_ARG = -1,        // bad argument (null pointer, unsupported shape)
+  SST_ERR_UNSUPPORTED = -2,
+  SST_ERR_HIP = -3,        // a HIP runtime call / launch failed
+};
+
+int sst_set_error(int code, const char* fmt, ...);
+
+#define SST_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return sst_set_error(SST_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define SST_LAUNCH_CHECK(name)                                                                   \
+  do {                                                                                           \
+    hipError_t e_ = hipGetLastError();                                                           \
+    if (e_ != hipSuccess) return sst_set_error(SST_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline hipStream_t sst_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- device helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a workgroup of NT threads (NT multiple of 64, <= 1024); result valid in every thread.
+// `red` is LDS scratch of at least NT/64 floats.  Deterministic order.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t += red[i];
+  return t;
+}
+
+// Agent-scope hand-off used by "last block reduces" epilogues (cdna guide, Guideline 16):
+// the single publishing lane stores its partial(s), releases, then takes a ticket.
+__device__ __forceinline__ unsigned publish_and_ticket(unsigned* counter) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void acquire_after_ticket() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ float load_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}

@@ -1,0 +1,69 @@
+"""ctypes binding of libsrganst.so (the C ABI declared in include/srganst.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object is missing
+or a call fails, this module raises - loudly - instead of routing anywhere else.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsrganst.so")
+
+P = c_void_p  # device pointer
+
+# name -> (restype, argtypes).  Kept in sync with include/srganst.h (tests/test_abi_symbols.py).
+SIGNATURES = {
+    "sst_last_error": (c_char_p, []),
+    "sst_version": (c_int, []),
+    "sst_arch": (c_char_p, []),
+    "sst_st_loss_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64)]),
+    "sst_st_loss_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_int, P]),
+    "sst_st_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+}
+
+_lib = None
+
+
+class HipPathError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipPathError(
+                f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C srgan-st_amd/csrc).  There is no CPU fallback for the HIP path.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)           # AttributeError if the .so is stale: also loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().sst_last_error().decode(errors="replace")
+        raise HipPathError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipPathError("HIP path needs tensors on a ROCm device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise HipPathError("HIP path needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
