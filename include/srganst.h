@@ -33,6 +33,54 @@ int sst_st_loss_bwd(const float* sr, const float* gS, float* dsr, const float* s
                     float scale_host, int accumulate, int B, int H, int W, float sigma, float rho,
                     void* stream);
 
+/* ---- convolution (fp32 MFMA implicit GEMM, NHWC) --------------------------------------------------
+ * Replaces the cuDNN/oneDNN kernels behind nn.Conv2d fwd/bwd of model.py:32-56,101,113,127,159,173,176.
+ * Weights are consumed in a fragment-major packed layout produced by sst_conv_pack from the reference
+ * layout [Cout][Cin][k][k]:  mode 0 = forward, mode 1 = data-gradient of a stride-1 conv (transposed,
+ * rotated 180 deg; then outputs = Cin, inputs = Cout).
+ * in_act: 0 none, 1 slope activation (PReLU scalar / LeakyReLU / ReLU=slope 0) applied to
+ *         x*in_scale+in_shift while staging (the producer's BatchNorm-apply + activation, fused).
+ * out_mode: 0 NHWC, 1 PixelShuffle(2) store (model.py:160), 2 NCHW + clamp(0,1) with pre-clamp copy
+ *           (model.py:148-150), 3 inverse pixel-shuffle store.
+ * stats: per-tile BatchNorm partials [sst_conv_mtiles][2][Cout] (sum, centred M2), stats_cnt [mtiles]. */
+int64_t sst_conv_packed_floats(int Cout, int Cin, int ksize);
+int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksize, int mode, void* stream);
+int sst_conv_mtiles(int B, int Ho, int Wo);
+int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,
+                 const float* in_scale, const float* in_shift, const float* in_slope,
+                 float in_slope_const, int in_act, const float* residual, float* stats,
+                 float* stats_cnt, int out_mode, int B, int H, int W, int Cin, int Cout, int ksize,
+                 int stride, void* stream);
+/* dW[Cout][Cin][k][k] (+)= sum_pixels X'(shifted) * dY ; slab = sst_conv_wgrad_chunks*k*k*Cout*Cin floats */
+int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int ksize);
+int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
+                   const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
+                   int B, int H, int W, int Cin, int Cout, int stride, int ksize, int accumulate,
+                   void* stream);
+
+/* ---- BatchNorm (train mode) + elementwise glue, tensors viewed as [R rows, C channels] -----------
+ * nn.BatchNorm2d model.py:36-57,114,174,177 (eps 1e-5, momentum .1); PReLU/LeakyReLU backward;
+ * residual adds model.py:146,183. */
+int sst_bn_finalize(const float* stats, const float* cnt, int ntiles, int C, const float* gamma,
+                    const float* beta, float* run_mean, float* run_var, float* mean, float* rstd,
+                    float* scale, float* shift, float eps, float momentum, void* stream);
+int sst_bn_eval_affine(const float* gamma, const float* beta, const float* run_mean,
+                       const float* run_var, float* scale, float* shift, int C, float eps, void* stream);
+int sst_bn_residual(const float* y, const float* scale, const float* shift, const float* res,
+                    const float* res_slope, float* out, int64_t R, int C, void* stream);
+int sst_bwd_reduce_blocks(int64_t R, int C);
+int sst_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale,
+                   const float* shift, const float* slope, float slope_const, int act, float* partial,
+                   int64_t R, int C, void* stream);
+int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean,
+                     const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
+                     float* cB, float* cC, float* dslope, int accumulate, void* stream);
+int sst_bwd_apply(const float* g, const float* g2, const float* y, const float* scale,
+                  const float* shift, const float* slope, float slope_const, int act, const float* cA,
+                  const float* cB, const float* cC, float* dy, int64_t R, int C, void* stream);
+int sst_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int sst_slab_reduce(const float* slabs, float* out, int nslab, int64_t n, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

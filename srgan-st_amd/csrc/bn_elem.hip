@@ -1,0 +1,337 @@
+// BatchNorm (train mode) statistics / backward reductions and the elementwise glue of the
+// generator / discriminator graphs, NHWC fp32 viewed as [R = B*H*W rows, C channels].
+//
+// Replaces (reference file:line)
+//   nn.BatchNorm2d in train mode        model.py:36-57,114,174,177  (eps 1e-5, momentum 0.1, unbiased running_var)
+//   nn.PReLU / nn.LeakyReLU backward    model.py:102,161,175 / 33-58
+//   residual adds                       model.py:146,183
+// All reductions are two-stage with a fixed order (no atomics): bit-reproducible.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------------------------------------
+// Forward finalize: per-tile (sum, M2, count) partials of a conv output -> batch mean / rstd, the
+// fused affine (scale = gamma*rstd, shift = beta - mean*scale) and the running-stat update.
+// One workgroup per channel.
+__global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ cnt,
+                                                         int ntiles, int C, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                         float* __restrict__ run_var, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, float* __restrict__ scale,
+                                                         float* __restrict__ shift, float eps, float momentum) {
+  __shared__ float red[NT / 64];
+  const int c = blockIdx.x;
+  float s = 0.f, n = 0.f;
+  for (int t = threadIdx.x; t < ntiles; t += NT) {
+    s += stats[(size_t)t * 2 * C + c];
+    n += cnt[t];
+  }
+  s = block_sum<NT>(s, red);
+  n = block_sum<NT>(n, red);
+  const float mean = s / n;
+  float m2 = 0.f;
+  for (int t = threadIdx.x; t < ntiles; t += NT) {
+    const float nt = cnt[t];
+    const float d = stats[(size_t)t * 2 * C + c] / nt - mean;
+    m2 += stats[(size_t)t * 2 * C + C + c] + nt * d * d;   // Chan et al. parallel variance
+  }
+  m2 = block_sum<NT>(m2, red);
+  if (threadIdx.x == 0) {
+    const float var = m2 / n;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (run_mean) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (m2 / fmaxf(n - 1.f, 1.f));
+    }
+  }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float sc = gamma[c] / sqrtf(run_var[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - run_mean[c] * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out = y*scale + shift + act(res)        (residual add after a BatchNorm; act = optional slope activation)
+__global__ __launch_bounds__(NT) void bn_residual_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ res,
+                                                         const float* __restrict__ res_slope, float* __restrict__ out,
+                                                         int64_t R, int C) {
+  const int c4n = C >> 2;
+  const int64_t total = R * c4n;
+  const float sl = res_slope ? res_slope[0] : 1.f;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+    const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float rr = r[j];
+      if (res_slope) rr = rr > 0.f ? rr : rr * sl;
+      o[j] = fmaf(v[j], scale[c + j], shift[c + j]) + rr;
+    }
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward reductions over rows.  With z = y*scale+shift (or z = y when scale == null) and
+// gz = g * (act ? (z > 0 ? 1 : slope) : 1):
+//   partial[blk][0][c] = sum gz          partial[blk][1][c] = sum gz*y        partial[blk][2][c] = sum g*min(z,0)
+// Thread layout: C/4 float4-columns x (NT / (C/4)) row lanes.
+__global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ g2,
+                                                        const float* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const float* __restrict__ slope_p,
+                                                        float slope_c, int act, float* __restrict__ partial, int64_t R,
+                                                        int C, int rows_per_block) {
+  extern __shared__ float sm[];  // [rowlanes][3][C]
+  const int c4n = C >> 2;
+  const int rowlanes = NT / c4n;
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const int c = cl * 4;
+  const float slope = slope_p ? slope_p[0] : slope_c;
+  f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+  if (scale) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = scale[c + j];
+      sh[j] = shift[c + j];
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(R, r0 + rows_per_block);
+  if (rl < rowlanes) {
+    for (int64_t r = r0 + rl; r < r1; r += rowlanes) {
+      f32x4 gv = reinterpret_cast<const f32x4*>(g)[r * c4n + cl];
+      if (g2) gv += reinterpret_cast<const f32x4*>(g2)[r * c4n + cl];
+      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[r * c4n + cl];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = fmaf(yv[j], sc[j], sh[j]);
+        float gz = gv[j];
+        if (act) {
+          s2[j] += gz * fminf(z, 0.f);
+          gz = z > 0.f ? gz : gz * slope;
+        }
+        s0[j] += gz;
+        s1[j] += gz * yv[j];
+      }
+    }
+    float* d = sm + (size_t)rl * 3 * C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      d[c + j] = s0[j];
+      d[C + c + j] = s1[j];
+      d[2 * C + c + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += NT) {
+    float t = 0.f;
+    for (int q = 0; q < rowlanes; ++q) t += sm[(size_t)q * 3 * C + i];
+    partial[(size_t)blockIdx.x * 3 * C + i] = t;
+  }
+}
+
+// Finalize of the above.  If mean != null (BatchNorm): writes dgamma, dbeta and the coefficients of
+//   dy = cA[c]*gz + cB[c]*y + cC[c]          (gz as defined above)
+// else (no BN: bias-only layer): writes dbias = sum gz.   dslope (scalar) += sum_c partial[2] when dslope != null.
+__global__ __launch_bounds__(NT) void bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float n,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float* __restrict__ cA,
+                                                          float* __restrict__ cB, float* __restrict__ cC,
+                                                          float* __restrict__ dslope, int accumulate) {
+  __shared__ float red[NT / 64];
+  float al = 0.f;
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+      s0 += partial[(size_t)b * 3 * C + c];
+      s1 += partial[(size_t)b * 3 * C + C + c];
+      s2 += partial[(size_t)b * 3 * C + 2 * C + c];
+    }
+    al += s2;
+    if (mean) {
+      const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+      const float sgh = rs * (s1 - mu * s0);   // sum gz * yhat
+      const float m1 = s0 / n, m2 = sgh / n;
+      if (accumulate) {
+        dgamma[c] += sgh;
+        dbeta[c] += s0;
+      } else {
+        dgamma[c] = sgh;
+        dbeta[c] = s0;
+      }
+      const float a = ga * rs;
+      cA[c] = a;
+      cB[c] = -a * rs * m2;
+      cC[c] = -a * m1 + a * rs * mu * m2;
+    } else if (dbeta) {
+      if (accumulate) dbeta[c] += s0; else dbeta[c] = s0;
+    }
+  }
+  al = block_sum<NT>(al, red);
+  if (dslope && threadIdx.x == 0) {
+    if (accumulate) dslope[0] += al; else dslope[0] = al;
+  }
+}
+
+// dy = cA*gz + cB*y + cC  (BatchNorm input gradient), or dy = gz when cA == null (activation only).
+__global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ g2,
+                                                       const float* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ slope_p,
+                                                       float slope_c, int act, const float* __restrict__ cA,
+                                                       const float* __restrict__ cB, const float* __restrict__ cC,
+                                                       float* __restrict__ dy, int64_t R, int C) {
+  const int c4n = C >> 2;
+  const int64_t total = R * c4n;
+  const float slope = slope_p ? slope_p[0] : slope_c;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int c = (int)(i % c4n) * 4;
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    if (g2) gv += reinterpret_cast<const f32x4*>(g2)[i];
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gz = gv[j];
+      if (act) {
+        const float z = scale ? fmaf(yv[j], scale[c + j], shift[c + j]) : yv[j];
+        gz = z > 0.f ? gz : gz * slope;
+      }
+      o[j] = cA ? fmaf(cA[c + j], gz, fmaf(cB[c + j], yv[j], cC[c + j])) : gz;
+    }
+    reinterpret_cast<f32x4*>(dy)[i] = o;
+  }
+}
+
+// out[i] = a[i] + b[i]
+__global__ __launch_bounds__(NT) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ out, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT)
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+}
+
+// Sum of nslab consecutive slabs of n floats:  out[i] (+)= sum_s slabs[s*n + i]    (split-K wgrad reduction)
+__global__ __launch_bounds__(NT) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int nslab,
+                                                         int64_t n, int accumulate) {
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    float t = 0.f;
+    for (int s = 0; s < nslab; ++s) t += slabs[(size_t)s * n + i];
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
+inline int grid_for(int64_t work_items) {
+  int64_t b = (work_items + NT - 1) / NT;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+SST_API int sst_bn_finalize(const float* stats, const float* cnt, int ntiles, int C, const float* gamma, const float* beta,
+                            float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
+                            float eps, float momentum, void* stream) {
+  SST_REQUIRE(stats && cnt && gamma && beta && mean && rstd && scale && shift && ntiles > 0 && C > 0,
+              "sst_bn_finalize: bad argument");
+  SST_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "sst_bn_finalize: running stats must come together");
+  bn_finalize_kernel<<<C, NT, 0, sst_stream(stream)>>>(stats, cnt, ntiles, C, gamma, beta, run_mean, run_var, mean, rstd,
+                                                        scale, shift, eps, momentum);
+  SST_LAUNCH_CHECK("bn_finalize_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_bn_eval_affine(const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+                               float* scale, float* shift, int C, float eps, void* stream) {
+  SST_REQUIRE(gamma && beta && run_mean && run_var && scale && shift && C > 0, "sst_bn_eval_affine: bad argument");
+  bn_eval_affine_kernel<<<(C + 63) / 64, 64, 0, sst_stream(stream)>>>(gamma, beta, run_mean, run_var, scale, shift, C, eps);
+  SST_LAUNCH_CHECK("bn_eval_affine_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_bn_residual(const float* y, const float* scale, const float* shift, const float* res,
+                            const float* res_slope, float* out, int64_t R, int C, void* stream) {
+  SST_REQUIRE(y && scale && shift && res && out && R > 0 && C > 0 && (C & 3) == 0, "sst_bn_residual: bad argument");
+  bn_residual_kernel<<<grid_for(R * (C / 4)), NT, 0, sst_stream(stream)>>>(y, scale, shift, res, res_slope, out, R, C);
+  SST_LAUNCH_CHECK("bn_residual_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
+  // enough blocks to fill the chip, at least 32 rows each
+  int64_t nb = (R + 31) / 32;
+  if (nb > 512) nb = 512;
+  return (int)(nb < 1 ? 1 : nb);
+}
+
+SST_API int sst_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                           const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
+                           void* stream) {
+  SST_REQUIRE(g && y && partial && R > 0 && C >= 4 && (C & 3) == 0 && C <= 1024, "sst_bwd_reduce: bad argument (C=%d)", C);
+  SST_REQUIRE(NT % (C / 4) == 0 || C / 4 > NT, "sst_bwd_reduce: C/4 must divide %d", NT);
+  SST_REQUIRE(C / 4 <= NT, "sst_bwd_reduce: C too large");
+  const int nblk = sst_bwd_reduce_blocks(R, C);
+  const int rpb = (int)((R + nblk - 1) / nblk);
+  const int rowlanes = NT / (C / 4);
+  const size_t smem = (size_t)rowlanes * 3 * C * sizeof(float);
+  bwd_reduce_kernel<<<nblk, NT, smem, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C,
+                                                             rpb);
+  SST_LAUNCH_CHECK("bwd_reduce_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean, const float* rstd,
+                             const float* gamma, float* dgamma, float* dbeta, float* cA, float* cB, float* cC,
+                             float* dslope, int accumulate, void* stream) {
+  SST_REQUIRE(partial && nblk > 0 && C > 0, "sst_bwd_finalize: bad argument");
+  SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize: BN mode needs all BN pointers");
+  bwd_finalize_kernel<<<1, NT, 0, sst_stream(stream)>>>(partial, nblk, C, n, mean, rstd, gamma, dgamma, dbeta, cA, cB, cC,
+                                                        dslope, accumulate);
+  SST_LAUNCH_CHECK("bwd_finalize_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_bwd_apply(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                          const float* slope, float slope_const, int act, const float* cA, const float* cB,
+                          const float* cC, float* dy, int64_t R, int C, void* stream) {
+  SST_REQUIRE(g && y && dy && R > 0 && C > 0 && (C & 3) == 0, "sst_bwd_apply: bad argument");
+  bwd_apply_kernel<<<grid_for(R * (C / 4)), NT, 0, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, cA,
+                                                                        cB, cC, dy, R, C);
+  SST_LAUNCH_CHECK("bwd_apply_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  SST_REQUIRE(a && b && out && n > 0 && (n & 3) == 0, "sst_add: bad argument");
+  add_kernel<<<grid_for(n / 4), NT, 0, sst_stream(stream)>>>(a, b, out, n / 4);
+  SST_LAUNCH_CHECK("add_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_slab_reduce(const float* slabs, float* out, int nslab, int64_t n, int accumulate, void* stream) {
+  SST_REQUIRE(slabs && out && nslab > 0 && n > 0, "sst_slab_reduce: bad argument");
+  slab_reduce_kernel<<<grid_for(n), NT, 0, sst_stream(stream)>>>(slabs, out, nslab, n, accumulate);
+  SST_LAUNCH_CHECK("slab_reduce_kernel");
+  return SST_OK;
+}

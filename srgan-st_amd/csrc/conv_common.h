@@ -1,0 +1,27 @@
+// Shared pieces of the fp32-MFMA implicit-GEMM convolution kernels (gfx950).
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain (no TF32/bf16 anywhere), so the
+// only difference from the reference's fp32 conv is summation order.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CONV_NT = 256;   // threads per workgroup (4 waves)
+constexpr int CB = 64;         // input-channel block staged in LDS at a time
+constexpr int LDSC = CB + 4;   // padded per-pixel stride in LDS (floats): keeps 16-B alignment, spreads banks
+
+// activation applied to the conv INPUT while it is staged (fusion of the producer's BN-apply + activation)
+enum : int { ACT_NONE = 0, ACT_SLOPE = 1 /* x>0 ? x : slope*x  (PReLU scalar / LeakyReLU / ReLU with slope 0) */ };
+
+// Packed weight layout for the MFMA B operand ("fragment-major"):
+//   idx(o, i, tap) = ((((o/32 * NCB + i/64) * KK + tap) * 8 + (i%64)/8) * 64 + ((i%8)/4)*32 + o%32) * 4 + i%4
+// so that one wave's B fragment for (32 outputs, 8 inputs, one tap) is 1 KiB contiguous and lane l reads 16 B at l*16.
+__host__ __device__ inline int64_t packed_index(int o, int i, int tap, int ncb, int kk) {
+  return ((((int64_t)(o >> 5) * ncb + (i >> 6)) * kk + tap) * 8 + ((i & 63) >> 3)) * 256 + (((i & 7) >> 2) * 32 + (o & 31)) * 4 +
+         (i & 3);
+}
+__host__ __device__ inline int64_t packed_floats(int cout, int cin, int kk) {
+  return (int64_t)((cout + 31) / 32) * ((cin + 63) / 64) * kk * 8 * 256;
+}

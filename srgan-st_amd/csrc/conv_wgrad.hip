@@ -1,0 +1,176 @@
+// Weight gradient of the 3x3 (or any KSxKS, pad KS/2) NHWC convolution: fp32 MFMA, split-K over pixel chunks.
+//
+// Replaces autograd's cuDNN/oneDNN wgrad for every nn.Conv2d of the hot path (reference model.py:32-56,
+// 113,159,173,176):     dW[co][ci][ky][kx] = sum_{b,oy,ox} X'[b, oy*S+ky-P, ox*S+kx-P, ci] * dY[b,oy,ox,co]
+// where X' = act(x*in_scale+in_shift) is the conv's (virtual, re-computed while staging) input.
+//
+// GEMM view per tap: M = Cout, N = Cin, K = pixels.  Workgroup = (pixel chunk, tap, 64x64 block of
+// (co,ci)); wave w owns one 32x32 v_mfma_f32_32x32x2_f32 accumulator.  Pixel sub-tiles of 64 are
+// staged in LDS ([px][channel], so both MFMA operands are conflict-free ds_read_b32 columns).
+// Each workgroup writes its partial 64x64 tile to a slab [chunk][tap][Cout][Cin]; wgrad_reduce sums the
+// chunks in fixed order into the reference layout [Cout][Cin][KS][KS]  (no atomics: reproducible).
+#include "conv_common.h"
+
+namespace {
+
+constexpr int SUB = 64;          // pixels per staged sub-tile
+constexpr int WLD = 64 + 4;      // LDS row stride (floats)
+
+struct WgradArgs {
+  const float* x;          // [B,H,W,Cin]
+  const float* dy;         // [B,Ho,Wo,Cout]
+  float* slab;             // [nchunk][KK][Cout][Cin]
+  const float* in_scale;   // [Cin] or null
+  const float* in_shift;
+  const float* in_slope;   // device scalar or null
+  float in_slope_const;
+  int in_act;
+  int B, H, W, Cin, Cout, Ho, Wo, stride, KS, pad;
+  int chunk_px;            // pixels per chunk (multiple of SUB)
+};
+
+__global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float sX[SUB * WLD];
+  __shared__ __attribute__((aligned(16))) float sD[SUB * WLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tap = blockIdx.y, ky = tap / a.KS, kx = tap - ky * a.KS;
+  const int nci = (a.Cin + 63) / 64;
+  const int cob = blockIdx.z / nci, cib = blockIdx.z - cob * nci;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+  const int64_t m_begin = (int64_t)blockIdx.x * a.chunk_px;
+  const int64_t m_end = min(M, m_begin + a.chunk_px);
+  const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
+  const bool xvec = (a.Cin & 3) == 0, dvec = (a.Cout & 3) == 0;
+  const int wco = (wave & 1) * 32, wci = (wave >> 1) * 32;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int64_t m0 = m_begin; m0 < m_end; m0 += SUB) {
+    __syncthreads();
+    // ---- stage 64 pixels x 64 channels of X' (shifted by the tap) and of dY
+    for (int q = tid; q < SUB * 16; q += CONV_NT) {
+      const int p = q >> 4, c4 = (q & 15) * 4;
+      const int64_t m = m0 + p;
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        const int b = (int)(m / ((int64_t)a.Ho * a.Wo));
+        const int rem = (int)(m - (int64_t)b * a.Ho * a.Wo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+        const int c = ci0 + c4;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.Cin) {
+          const float* src = a.x + (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + c;
+          if (xvec) {
+            xv = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (c + j < a.Cin) xv[j] = src[j];
+          }
+          if (a.in_scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (c + j < a.Cin) xv[j] = fmaf(xv[j], a.in_scale[c + j], a.in_shift[c + j]);
+          }
+          if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = xv[j] > 0.f ? xv[j] : xv[j] * slope;
+          }
+          if (!xvec) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (c + j >= a.Cin) xv[j] = 0.f;
+          }
+        }
+        const int co = co0 + c4;
+        if (co < a.Cout) {
+          const float* src = a.dy + (size_t)m * a.Cout + co;
+          if (dvec) {
+            dv = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (co + j < a.Cout) dv[j] = src[j];
+          }
+        }
+      }
+      *reinterpret_cast<f32x4*>(&sX[p * WLD + c4]) = xv;
+      *reinterpret_cast<f32x4*>(&sD[p * WLD + c4]) = dv;
+    }
+    __syncthreads();
+    // ---- 32 MFMAs: K = 64 pixels, 2 per instruction (lane half lh picks the pixel of the pair)
+#pragma unroll 8
+    for (int kk = 0; kk < SUB / 2; ++kk) {
+      const float av = sD[(2 * kk + lh) * WLD + wco + li];
+      const float bv = sX[(2 * kk + lh) * WLD + wci + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  // ---- store the partial tile: rows = co, cols = ci (lanes contiguous along ci)
+  float* out = a.slab + ((size_t)blockIdx.x * gridDim.y + tap) * a.Cout * a.Cin;
+  const int ci = ci0 + wci + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (co < a.Cout && ci < a.Cin) out[(size_t)co * a.Cin + ci] = acc[r];
+  }
+}
+
+// dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunk,
+                                                           int KK, int Cout, int Cin, int accumulate) {
+  const int64_t per_tap = (int64_t)Cout * Cin, total = per_tap * KK;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int tap = (int)(i / per_tap);
+    const int64_t oc = i - (int64_t)tap * per_tap;   // co*Cin + ci
+    float t = 0.f;
+    for (int s = 0; s < nchunk; ++s) t += slab[(size_t)s * total + i];
+    float* d = dw + oc * KK + tap;
+    *d = accumulate ? *d + t : t;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+// Number of pixel chunks the wgrad kernel will use for this shape (slab floats = chunks*KS*KS*Cout*Cin).
+SST_API int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int ksize) {
+  const int64_t M = (int64_t)B * Ho * Wo;
+  const int nblk = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+  int64_t want = (768 + ksize * ksize * nblk - 1) / (ksize * ksize * nblk);   // ~3 workgroups per CU
+  int64_t maxc = (M + SUB - 1) / SUB;
+  if (want > maxc) want = maxc;
+  if (want < 1) want = 1;
+  int64_t chunk_px = ((M + want - 1) / want + SUB - 1) / SUB * SUB;
+  return (int)((M + chunk_px - 1) / chunk_px);
+}
+
+SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
+                           const float* in_shift, const float* in_slope, float in_slope_const, int in_act, int B, int H,
+                           int W, int Cin, int Cout, int stride, int ksize, int accumulate, void* stream) {
+  SST_REQUIRE(x && dy && slab && dw, "sst_conv_wgrad: null pointer");
+  SST_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize & 1) && ksize <= 9,
+              "sst_conv_wgrad: bad shape");
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.slab = slab; a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
+  a.in_slope_const = in_slope_const; a.in_act = in_act;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.KS = ksize; a.pad = ksize / 2;
+  a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
+  a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+  const int64_t M = (int64_t)B * a.Ho * a.Wo;
+  const int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
+  a.chunk_px = (int)(((M + nchunk - 1) / nchunk + SUB - 1) / SUB * SUB);
+  const int KK = ksize * ksize;
+  dim3 grid(nchunk, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
+  conv_wgrad_kernel<<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+  SST_LAUNCH_CHECK("conv_wgrad_kernel");
+  const int64_t total = (int64_t)KK * Cout * Cin;
+  const int rb = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  wgrad_reduce_kernel<<<rb, 256, 0, sst_stream(stream)>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate);
+  SST_LAUNCH_CHECK("wgrad_reduce_kernel");
+  return SST_OK;
+}

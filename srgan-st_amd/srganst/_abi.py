@@ -22,6 +22,23 @@ SIGNATURES = {
     "sst_st_loss_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64)]),
     "sst_st_loss_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_int, P]),
     "sst_st_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "sst_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
+    "sst_conv_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_mtiles": (c_int, [c_int, c_int, c_int]),
+    "sst_conv_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_int,
+                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_wgrad_chunks": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sst_conv_wgrad": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, P]),
+    "sst_bn_finalize": (c_int, [P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_float, c_float, P]),
+    "sst_bn_eval_affine": (c_int, [P, P, P, P, P, P, c_int, c_float, P]),
+    "sst_bn_residual": (c_int, [P, P, P, P, P, P, c_int64, c_int, P]),
+    "sst_bwd_reduce_blocks": (c_int, [c_int64, c_int]),
+    "sst_bwd_reduce": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P]),
+    "sst_bwd_finalize": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P]),
+    "sst_bwd_apply": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int64, c_int, P]),
+    "sst_add": (c_int, [P, P, P, c_int64, P]),
+    "sst_slab_reduce": (c_int, [P, P, c_int, c_int64, c_int, P]),
 }
 
 _lib = None

@@ -1,0 +1,139 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per entry point).
+
+Activations are NHWC fp32 here; weights arrive in the reference layout [Cout,Cin,k,k] and are
+packed by ``pack_conv``.  Used by the model graphs (gen_graph.py / disc_graph.py) and by the
+per-kernel parity tests.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _abi
+from ._abi import check, ptr, stream_ptr
+
+OUT_NHWC, OUT_SHUFFLE, OUT_NCHW_CLAMP, OUT_UNSHUFFLE = 0, 1, 2, 3
+ACT_NONE, ACT_SLOPE = 0, 1
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _f32(*shape, like):
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+def pack_conv(w: torch.Tensor, mode: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+    cout, cin, k, _ = w.shape
+    o, i = (cin, cout) if mode else (cout, cin)
+    n = _abi.lib().sst_conv_packed_floats(o, i, k)
+    if out is None:
+        out = _f32(n, like=w)
+    assert out.numel() == n
+    check(_abi.lib().sst_conv_pack(ptr(w), ptr(out), cout, cin, k, mode, stream_ptr()), "sst_conv_pack")
+    return out
+
+
+def conv_out_hw(h, w, k, stride):
+    p = k // 2
+    return (h + 2 * p - k) // stride + 1, (w + 2 * p - k) // stride + 1
+
+
+def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=None, in_slope=None,
+             in_slope_const=0.0, in_act=ACT_NONE, residual=None, want_stats=False, out_mode=OUT_NHWC,
+             want_pre=False):
+    """x [B,H,W,Cin] NHWC -> y (layout per out_mode); returns (y, y_pre|None, stats|None, cnt|None)."""
+    B, H, W, cin = x.shape
+    ho, wo = conv_out_hw(H, W, ksize, stride)
+    if out_mode == OUT_NHWC:
+        y = _f32(B, ho, wo, cout, like=x)
+    elif out_mode == OUT_SHUFFLE:
+        y = _f32(B, 2 * ho, 2 * wo, cout // 4, like=x)
+    elif out_mode == OUT_NCHW_CLAMP:
+        y = _f32(B, cout, ho, wo, like=x)
+    else:
+        y = _f32(B, ho // 2, wo // 2, cout * 4, like=x)
+    y_pre = torch.empty_like(y) if want_pre else None
+    stats = cnt = None
+    if want_stats:
+        mt = _abi.lib().sst_conv_mtiles(B, ho, wo)
+        stats = _f32(mt, 2, cout, like=x)
+        cnt = _f32(mt, like=x)
+    check(_abi.lib().sst_conv_fwd(ptr(x), ptr(wp), ptr(y), ptr(y_pre), ptr(bias), ptr(in_scale), ptr(in_shift),
+                                  ptr(in_slope), float(in_slope_const), int(in_act), ptr(residual), ptr(stats), ptr(cnt),
+                                  int(out_mode), B, H, W, cin, cout, ksize, stride, stream_ptr()), "sst_conv_fwd")
+    return y, y_pre, stats, cnt
+
+
+def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,
+               in_act=ACT_NONE, accumulate=False):
+    """dw_out [Cout,Cin,k,k] (reference layout) (+)= wgrad.  x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC."""
+    B, H, W, cin = x.shape
+    cout = dy.shape[-1]
+    ho, wo = conv_out_hw(H, W, ksize, stride)
+    assert tuple(dy.shape) == (B, ho, wo, cout) and tuple(dw_out.shape) == (cout, cin, ksize, ksize)
+    nch = _abi.lib().sst_conv_wgrad_chunks(B, ho, wo, cin, cout, ksize)
+    slab = _f32(nch * ksize * ksize * cout * cin, like=x)
+    check(_abi.lib().sst_conv_wgrad(ptr(x), ptr(dy), ptr(slab), ptr(dw_out), ptr(in_scale), ptr(in_shift), ptr(in_slope),
+                                    float(in_slope_const), int(in_act), B, H, W, cin, cout, stride, ksize,
+                                    int(accumulate), stream_ptr()), "sst_conv_wgrad")
+    return dw_out
+
+
+def bn_finalize(stats, cnt, gamma, beta, run_mean=None, run_var=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """-> (mean, rstd, scale, shift); updates run_mean/run_var in place when given (train mode)."""
+    C = gamma.numel()
+    mean, rstd, scale, shift = (_f32(C, like=gamma) for _ in range(4))
+    check(_abi.lib().sst_bn_finalize(ptr(stats), ptr(cnt), stats.shape[0], C, ptr(gamma), ptr(beta), ptr(run_mean),
+                                     ptr(run_var), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), eps, momentum,
+                                     stream_ptr()), "sst_bn_finalize")
+    return mean, rstd, scale, shift
+
+
+def bn_eval_affine(gamma, beta, run_mean, run_var, eps=BN_EPS):
+    C = gamma.numel()
+    scale, shift = _f32(C, like=gamma), _f32(C, like=gamma)
+    check(_abi.lib().sst_bn_eval_affine(ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_var), ptr(scale), ptr(shift), C, eps,
+                                        stream_ptr()), "sst_bn_eval_affine")
+    return scale, shift
+
+
+def bn_residual(y, scale, shift, res, res_slope=None):
+    C = y.shape[-1]
+    out = torch.empty_like(y)
+    check(_abi.lib().sst_bn_residual(ptr(y), ptr(scale), ptr(shift), ptr(res), ptr(res_slope), ptr(out), y.numel() // C, C,
+                                     stream_ptr()), "sst_bn_residual")
+    return out
+
+
+def bwd_reduce(g, y, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0):
+    C = y.shape[-1]
+    R = y.numel() // C
+    nblk = _abi.lib().sst_bwd_reduce_blocks(R, C)
+    partial = _f32(nblk, 3, C, like=y)
+    check(_abi.lib().sst_bwd_reduce(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
+                                    ptr(partial), R, C, stream_ptr()), "sst_bwd_reduce")
+    return partial
+
+
+def bwd_finalize(partial, n, mean=None, rstd=None, gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False):
+    """BN mode (mean given): fills dgamma/dbeta, returns (cA,cB,cC).  Otherwise dbeta (= dbias) / dslope only."""
+    nblk, _, C = partial.shape
+    cA = cB = cC = None
+    if mean is not None:
+        cA, cB, cC = (_f32(C, like=partial) for _ in range(3))
+    check(_abi.lib().sst_bwd_finalize(ptr(partial), nblk, C, float(n), ptr(mean), ptr(rstd), ptr(gamma), ptr(dgamma), ptr(dbeta),
+                                      ptr(cA), ptr(cB), ptr(cC), ptr(dslope), int(accumulate), stream_ptr()),
+          "sst_bwd_finalize")
+    return cA, cB, cC
+
+
+def bwd_apply(g, y, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, cA=None, cB=None, cC=None):
+    C = y.shape[-1]
+    dy = torch.empty_like(y)
+    check(_abi.lib().sst_bwd_apply(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
+                                   ptr(cA), ptr(cB), ptr(cC), ptr(dy), y.numel() // C, C, stream_ptr()), "sst_bwd_apply")
+    return dy
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    check(_abi.lib().sst_add(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr()), "sst_add")
+    return out

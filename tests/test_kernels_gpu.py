@@ -1,0 +1,202 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against plain torch fp32/fp64 on CPU.
+
+Tolerance: the north star allows 1e-3 relative fp32; fp32 MFMA is an exact fp32 FMA chain so we
+hold the kernels to 2e-5 norm-wise against an fp64 reference (re-association only)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from srganst import ops
+    return ops
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride
+    (2, 24, 24, 64, 64, 3, 1),
+    (1, 13, 9, 8, 8, 3, 1),        # ragged tile edges, tiny channels (reduced golden config)
+    (2, 12, 12, 64, 256, 3, 1),
+    (2, 24, 24, 64, 64, 3, 2),
+    (1, 12, 12, 128, 256, 3, 2),   # two input-channel blocks
+    (1, 11, 7, 3, 64, 3, 1),       # Cin not a multiple of 4
+    (2, 24, 24, 3, 64, 9, 1),      # conv1
+    (1, 32, 24, 64, 3, 9, 1),      # conv3
+    (1, 16, 16, 256, 64, 3, 1),    # up-conv dgrad shape
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_plain(ops, case):
+    B, H, W, Cin, Cout, k, s = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), s, k // 2)
+    wp = ops.pack_conv(w.cuda(), 0)
+    y, _, _, _ = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, k, s, bias=b.cuda())
+    assert rel_err(nchw(y.cpu()), ref) < TOL
+
+
+def test_conv_fwd_fused_prologue_stats_residual(ops):
+    B, H, W, C = 2, 24, 24, 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / 24.0
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    slope = torch.tensor([0.25])
+    res = torch.randn(B, C, H, W, generator=g)
+    xin = F.prelu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), slope.double())
+    conv = F.conv2d(xin, w.double(), None, 1, 1)
+    ref = conv + res.double()
+    y, _, stats, cnt = ops.conv_fwd(nhwc(x).cuda(), ops.pack_conv(w.cuda()), C, 3, 1, in_scale=sc.cuda(), in_shift=sh.cuda(),
+                                    in_slope=slope.cuda(), in_act=ops.ACT_SLOPE, residual=nhwc(res).cuda(), want_stats=True)
+    assert rel_err(nchw(y.cpu()), ref) < TOL
+    # BN finalize on the stats of y (stats are taken on the stored value, i.e. incl. the residual)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    mean, rstd, scale, shift = ops.bn_finalize(stats, cnt, gamma.cuda(), beta.cuda(), (rm_d := rm.cuda()), (rv_d := rv.cuda()))
+    m_ref = ref.mean(dim=(0, 2, 3))
+    v_ref = ref.var(dim=(0, 2, 3), unbiased=False)
+    assert rel_err(mean.cpu(), m_ref) < TOL
+    assert rel_err(rstd.cpu(), 1 / torch.sqrt(v_ref + 1e-5)) < TOL
+    assert rel_err(scale.cpu(), gamma.double() / torch.sqrt(v_ref + 1e-5)) < TOL
+    assert rel_err(shift.cpu(), beta.double() - m_ref * gamma.double() / torch.sqrt(v_ref + 1e-5)) < 1e-4
+    bn = torch.nn.BatchNorm2d(C)
+    bn.train()
+    bn(ref.float())
+    assert torch.allclose(rm_d.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv_d.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_bn_stats_large_mean(ops):
+    """Chan-combined centred statistics stay accurate when |mean| >> std (naive E[x^2]-E[x]^2 would not)."""
+    B, H, W, C = 4, 24, 24, 64
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.zeros(C, C, 3, 3)
+    for c in range(C):
+        w[c, c, 1, 1] = 1.0
+    bias = torch.full((C,), 100.0)
+    y, _, stats, cnt = ops.conv_fwd(nhwc(x).cuda(), ops.pack_conv(w.cuda()), C, 3, 1, bias=bias.cuda(), want_stats=True)
+    mean, rstd, _, _ = ops.bn_finalize(stats, cnt, torch.ones(C).cuda(), torch.zeros(C).cuda())
+    ref = x.double() + 100.0
+    v = (x + 100.0).double().var(dim=(0, 2, 3), unbiased=False)
+    assert rel_err(rstd.cpu(), 1 / torch.sqrt(v + 1e-5)) < 1e-4
+
+
+def test_conv_shuffle_and_clamp_stores(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 12, 12, generator=g)
+    w = torch.randn(64, 16, 3, 3, generator=g) / 12.0
+    ref = F.pixel_shuffle(F.conv2d(x.double(), w.double(), None, 1, 1), 2)
+    y, _, _, _ = ops.conv_fwd(nhwc(x).cuda(), ops.pack_conv(w.cuda()), 64, 3, 1, out_mode=ops.OUT_SHUFFLE)
+    assert tuple(y.shape) == (2, 24, 24, 16) and rel_err(nchw(y.cpu()), ref) < TOL
+    # inverse store: unshuffle(conv) - feed the shuffled tensor through an identity 3x3
+    w2 = torch.randn(3, 16, 9, 9, generator=g) / 36.0
+    b2 = torch.randn(3, generator=g) * 0.5 + 0.5
+    pre = F.conv2d(ref, w2.double(), b2.double(), 1, 4)
+    yc, ypre, _, _ = ops.conv_fwd(y, ops.pack_conv(w2.cuda()), 3, 9, 1, bias=b2.cuda(), out_mode=ops.OUT_NCHW_CLAMP,
+                                  want_pre=True)
+    assert rel_err(ypre.cpu(), pre) < TOL
+    assert torch.equal(yc.cpu(), ypre.cpu().clamp(0, 1))
+    wi = torch.zeros(16, 16, 3, 3)
+    for c in range(16):
+        wi[c, c, 1, 1] = 1.0
+    yu, _, _, _ = ops.conv_fwd(y, ops.pack_conv(wi.cuda()), 16, 3, 1, out_mode=ops.OUT_UNSHUFFLE)
+    assert rel_err(nchw(yu.cpu()), F.pixel_unshuffle(ref, 2)) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64, 3), (1, 13, 9, 8, 8, 3), (1, 16, 16, 64, 256, 3), (1, 16, 16, 256, 64, 3),
+                                  (1, 20, 12, 64, 3, 9)])
+def test_conv_dgrad_via_mode1_pack(ops, case):
+    B, H, W, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    F.conv2d(x, w.double(), None, 1, k // 2).backward(dy.double())
+    wd = ops.pack_conv(w.cuda(), 1)
+    dx, _, _, _ = ops.conv_fwd(nhwc(dy).cuda(), wd, Cin, k, 1)
+    assert rel_err(nchw(dx.cpu()), x.grad) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64, 3, 1), (1, 13, 9, 8, 8, 3, 1), (2, 16, 16, 64, 256, 3, 1),
+                                  (2, 24, 24, 64, 128, 3, 2), (2, 24, 24, 3, 64, 9, 1), (1, 32, 24, 64, 3, 9, 1),
+                                  (1, 11, 7, 3, 64, 3, 1)])
+def test_conv_wgrad(ops, case):
+    B, H, W, Cin, Cout, k, s = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64, requires_grad=True)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    xin = F.leaky_relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2)
+    y = F.conv2d(xin, w, None, s, k // 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    dw = torch.full((Cout, Cin, k, k), 7.0).cuda()
+    ops.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw, k, s, in_scale=sc.cuda(), in_shift=sh.cuda(), in_slope_const=0.2,
+                   in_act=ops.ACT_SLOPE)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+    ops.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw, k, s, in_scale=sc.cuda(), in_shift=sh.cuda(), in_slope_const=0.2,
+                   in_act=ops.ACT_SLOPE, accumulate=True)
+    assert rel_err(dw.cpu(), 2 * w.grad) < TOL
+
+
+@pytest.mark.parametrize("C", [8, 64, 256])
+def test_bn_prelu_backward_chain(ops, C):
+    """conv-out y -> BN(train) -> PReLU -> (upstream g): dy, dgamma, dbeta, dslope vs autograd."""
+    B, H, W = 2, 12, 12
+    g = torch.Generator().manual_seed(6 + C)
+    y = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    slope = torch.tensor([0.25], dtype=torch.float64, requires_grad=True)
+    up = torch.randn(B, C, H, W, generator=g)
+    up2 = torch.randn(B, C, H, W, generator=g)
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    F.prelu(z, slope).backward((up + up2).double())
+    yf = y.detach().float()
+    mean = yf.double().mean(dim=(0, 2, 3))
+    var = yf.double().var(dim=(0, 2, 3), unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    scale = (gamma.detach() * rstd).float().cuda()
+    shift = (beta.detach() - mean * gamma.detach() * rstd).float().cuda()
+    yd, gd, g2d, sl = nhwc(yf).cuda(), nhwc(up).cuda(), nhwc(up2).cuda(), slope.detach().float().cuda()
+    part = ops.bwd_reduce(gd, yd, g2=g2d, scale=scale, shift=shift, slope=sl, act=1)
+    dgamma, dbeta, dslope = torch.empty(C).cuda(), torch.empty(C).cuda(), torch.empty(1).cuda()
+    cA, cB, cC = ops.bwd_finalize(part, B * H * W, mean.float().cuda(), rstd.float().cuda(), gamma.detach().float().cuda(),
+                                  dgamma, dbeta, dslope)
+    dy = ops.bwd_apply(gd, yd, g2=g2d, scale=scale, shift=shift, slope=sl, act=1, cA=cA, cB=cB, cC=cC)
+    assert rel_err(nchw(dy.cpu()), y.grad) < 1e-4
+    assert rel_err(dgamma.cpu(), gamma.grad) < 1e-4
+    assert rel_err(dbeta.cpu(), beta.grad) < 1e-4
+    assert rel_err(dslope.cpu(), slope.grad) < 1e-4
+
+
+def test_bn_residual_and_add(ops):
+    g = torch.Generator().manual_seed(9)
+    y, res = torch.randn(2, 8, 8, 64, generator=g), torch.randn(2, 8, 8, 64, generator=g)
+    sc, sh = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    sl = torch.tensor([0.3])
+    out = ops.bn_residual(y.cuda(), sc.cuda(), sh.cuda(), res.cuda(), sl.cuda())
+    ref = y * sc + sh + torch.where(res > 0, res, res * 0.3)
+    assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    out = ops.bn_residual(y.cuda(), sc.cuda(), sh.cuda(), res.cuda())
+    assert torch.allclose(out.cpu(), y * sc + sh + res, rtol=1e-6, atol=1e-6)
+    assert torch.equal(ops.add(y.cuda(), res.cuda()).cpu(), y + res)
