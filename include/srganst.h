@@ -77,9 +77,28 @@ int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float
                      float* cB, float* cC, float* dslope, int accumulate, void* stream);
 int sst_bwd_apply(const float* g, const float* g2, const float* y, const float* scale,
                   const float* shift, const float* slope, float slope_const, int act, const float* cA,
-                  const float* cB, const float* cC, float* dy, int64_t R, int C, void* stream);
+                  const float* cB, const float* cC, float* dy, int64_t R, int C, int unshuffle_H,
+                  int unshuffle_W, void* stream);
 int sst_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 int sst_slab_reduce(const float* slabs, float* out, int nslab, int64_t n, int accumulate, void* stream);
+
+/* ---- layout + criterions ------------------------------------------------------------------------
+ * sst_transpose: NCHW <-> NHWC (model.py:138-152 keeps an NCHW surface).  sst_clamp_bwd: backward of
+ * clamp_(0,1) model.py:150 fused with the NCHW->NHWC hand-off and the conv3 bias gradient.
+ * pixel criterion config.py:88-90 (mode 0 MSE / 1 L1); BCEWithLogits config.py:71-73, train.py:113-161. */
+int sst_transpose(const float* src, float* dst, int B, int C, int H, int W, int to_nchw, void* stream);
+int sst_clamp_bwd_blocks(int B, int H, int W);
+int sst_clamp_bwd(const float* g, const float* pre, float* out, float* partial, float* dbias,
+                  int accumulate, int B, int C, int H, int W, void* stream);
+int sst_pixel_loss_blocks(int64_t n);
+int sst_pixel_loss_fwd(const float* x, const float* gt, float* loss, float* partials, unsigned* counter,
+                       int64_t n, int mode, void* stream);
+int sst_pixel_loss_bwd(const float* x, const float* gt, float* dx, const float* scale_dev,
+                       float scale_host, int accumulate, int64_t n, int mode, void* stream);
+int sst_bce_logits(const float* logits, float target, float* loss, float* dlogits,
+                   const float* scale_dev, float scale_host, int n, void* stream);
+int sst_weighted_sum(const float* const* terms, const float* weights, int n, float* out, float* weighted,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ shift, const float* __restrict__ slope_p,
                                                        float slope_c, int act, const float* __restrict__ cA,
                                                        const float* __restrict__ cB, const float* __restrict__ cC,
-                                                       float* __restrict__ dy, int64_t R, int C) {
+                                                       float* __restrict__ dy, int64_t R, int C, int uH, int uW) {
   const int c4n = C >> 2;
   const int64_t total = R * c4n;
   const float slope = slope_p ? slope_p[0] : slope_c;
@@ -221,7 +221,18 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
       }
       o[j] = cA ? fmaf(cA[c + j], gz, fmaf(cB[c + j], yv[j], cC[c + j])) : gz;
     }
-    reinterpret_cast<f32x4*>(dy)[i] = o;
+    if (uW == 0) {
+      reinterpret_cast<f32x4*>(dy)[i] = o;
+    } else {  // inverse PixelShuffle(2) store: rows are pixels (b,Y,X) of the [B,uH,uW,C] shuffled tensor
+      const int64_t r = i / c4n;
+      const int X = (int)(r % uW);
+      const int64_t t = r / uW;
+      const int Y = (int)(t % uH);
+      const int64_t b = t / uH;
+      float* d = dy + (((b * (uH >> 1) + (Y >> 1)) * (uW >> 1) + (X >> 1)) * (int64_t)(4 * C)) + 2 * (Y & 1) + (X & 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[4 * (c + j)] = o[j];
+    }
   }
 }
 
@@ -314,10 +325,13 @@ SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, con
 
 SST_API int sst_bwd_apply(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
                           const float* slope, float slope_const, int act, const float* cA, const float* cB,
-                          const float* cC, float* dy, int64_t R, int C, void* stream) {
+                          const float* cC, float* dy, int64_t R, int C, int unshuffle_H, int unshuffle_W, void* stream) {
   SST_REQUIRE(g && y && dy && R > 0 && C > 0 && (C & 3) == 0, "sst_bwd_apply: bad argument");
+  SST_REQUIRE(unshuffle_W == 0 || ((unshuffle_H & 1) == 0 && (unshuffle_W & 1) == 0 &&
+                                   R % ((int64_t)unshuffle_H * unshuffle_W) == 0),
+              "sst_bwd_apply: bad unshuffle geometry");
   bwd_apply_kernel<<<grid_for(R * (C / 4)), NT, 0, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, cA,
-                                                                        cB, cC, dy, R, C);
+                                                                        cB, cC, dy, R, C, unshuffle_H, unshuffle_W);
   SST_LAUNCH_CHECK("bwd_apply_kernel");
   return SST_OK;
 }

@@ -1,0 +1,212 @@
+// Small layout / loss kernels around the generator and discriminator graphs (gfx950).
+//
+//   pixel (MSE / L1) criterion          reference config.py:88-90, warmup.py:88-93, train.py:138
+//   BCE-with-logits criterion           reference config.py:71-73, train.py:59,113-114,135-136,155-161
+//   clamp backward + NCHW<->NHWC        reference model.py:150 (clamp_), model.py:138-152 (NCHW surface)
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int NT = 256;
+
+// dst NHWC [B,H,W,C] <- src NCHW [B,C,H,W]   (dir 0)   or the inverse (dir 1).  Small C (3): plain gather.
+__global__ __launch_bounds__(NT) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C,
+                                                       int H, int W, int dir) {
+  const int64_t total = (int64_t)B * C * H * W, hw = (int64_t)H * W;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    if (dir == 0) {  // i indexes dst NHWC
+      const int c = (int)(i % C);
+      const int64_t p = i / C, b = p / hw, r = p - b * hw;
+      dst[i] = src[(b * C + c) * hw + r];
+    } else {         // i indexes dst NCHW
+      const int64_t r = i % hw, bc = i / hw, b = bc / C;
+      const int c = (int)(bc - b * C);
+      dst[i] = src[(b * hw + r) * C + c];
+    }
+  }
+}
+
+// g3[b,y,x,c] (NHWC) = (g[b,c,y,x] (+ g2)) * (0 <= pre <= 1)        clamp_ backward, model.py:150
+// and per-block partial column sums (-> bias gradient of the producing conv):  partial[blk][c]
+__global__ __launch_bounds__(NT) void clamp_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pre,
+                                                       float* __restrict__ out, float* __restrict__ partial, int B, int C,
+                                                       int H, int W) {
+  __shared__ float red[NT / 64];
+  const int64_t hw = (int64_t)H * W, npx = (int64_t)B * hw;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t p = blockIdx.x * (int64_t)NT + threadIdx.x; p < npx; p += (int64_t)gridDim.x * NT) {
+    const int64_t b = p / hw, r = p - b * hw;
+    for (int c = 0; c < C; ++c) {
+      const int64_t s = (b * C + c) * hw + r;
+      const float pv = pre[s];
+      const float v = (pv >= 0.f && pv <= 1.f) ? g[s] : 0.f;
+      out[p * C + c] = v;
+      if (c < 4) acc[c] += v;
+    }
+  }
+  for (int c = 0; c < C && c < 4; ++c) {
+    const float t = block_sum<NT>(acc[c], red);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * C + c] = t;
+  }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C,
+                                       int accumulate) {
+  const int c = threadIdx.x;
+  if (c < C) {
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += partial[(size_t)b * C + c];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+// ---- pixel criterion: mode 0 = MSE, 1 = L1.  Two-stage fixed-order reduction (last block finishes).
+__global__ __launch_bounds__(NT) void pixel_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                            float* __restrict__ loss, float* __restrict__ partials,
+                                                            unsigned* __restrict__ counter, int64_t n, int mode) {
+  __shared__ float red[NT / 64];
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[i], b = reinterpret_cast<const f32x4*>(gt)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = a[j] - b[j];
+      s += mode == 0 ? d * d : fabsf(d);
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += NT) {
+      const float d = x[i] - gt[i];
+      s += mode == 0 ? d * d : fabsf(d);
+    }
+  }
+  s = block_sum<NT>(s, red);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = s;
+    const unsigned t = publish_and_ticket(counter);
+    if (t == gridDim.x - 1) {
+      acquire_after_ticket();
+      float tot = 0.f;
+      for (unsigned i = 0; i < gridDim.x; ++i) tot += load_agent(partials + i);
+      loss[0] = tot / (float)n;
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// dx (+)= scale * d loss/dx ;  scale = scale_host * (scale_dev ? *scale_dev : 1)
+__global__ __launch_bounds__(NT) void pixel_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                            float* __restrict__ dx, const float* __restrict__ scale_dev,
+                                                            float scale_host, int accumulate, int64_t n, int mode) {
+  float sc = scale_host / (float)n;
+  if (scale_dev) sc *= scale_dev[0];
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const float d = x[i] - gt[i];
+    const float g = mode == 0 ? 2.f * d * sc : (d > 0.f ? sc : (d < 0.f ? -sc : 0.f));
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
+
+// ---- BCEWithLogits(mean) against a constant target t:  l = max(x,0) - x t + log1p(exp(-|x|))
+// single workgroup (logits are [B,1]); dlogit = scale * (sigmoid(x) - t) / n
+__global__ __launch_bounds__(NT) void bce_fwd_bwd_kernel(const float* __restrict__ x, float target, float* __restrict__ loss,
+                                                         float* __restrict__ dx, const float* __restrict__ scale_dev,
+                                                         float scale_host, int n) {
+  __shared__ float red[NT / 64];
+  float s = 0.f;
+  float sc = scale_host / (float)n;
+  if (scale_dev) sc *= scale_dev[0];
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float v = x[i];
+    s += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+    if (dx) dx[i] = sc * (1.f / (1.f + expf(-v)) - target);
+  }
+  s = block_sum<NT>(s, red);
+  if (threadIdx.x == 0 && loss) loss[0] = s / (float)n;
+}
+
+// out = sum_i w[i] * terms[i][0]     (weighted sum of up to 8 scalar losses; also copies each weighted term)
+struct ScalarPtrs { const float* p[8]; float w[8]; };
+__global__ void weighted_sum_kernel(ScalarPtrs sp, int n, float* __restrict__ out, float* __restrict__ weighted) {
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float v = sp.p[i][0] * sp.w[i];
+      if (weighted) weighted[i] = v;
+      t += v;
+    }
+    out[0] = t;
+  }
+}
+
+inline int grid_for(int64_t items) {
+  int64_t b = (items + NT - 1) / NT;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+SST_API int sst_transpose(const float* src, float* dst, int B, int C, int H, int W, int to_nchw, void* stream) {
+  SST_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "sst_transpose: bad argument");
+  transpose_kernel<<<grid_for((int64_t)B * C * H * W), NT, 0, sst_stream(stream)>>>(src, dst, B, C, H, W, to_nchw);
+  SST_LAUNCH_CHECK("transpose_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_clamp_bwd_blocks(int B, int H, int W) { return grid_for((int64_t)B * H * W); }
+
+// g, pre NCHW [B,C,H,W] (C <= 4) -> out NHWC [B,H,W,C]; dbias[C] (+)= column sums.  partial: blocks*C floats.
+SST_API int sst_clamp_bwd(const float* g, const float* pre, float* out, float* partial, float* dbias, int accumulate, int B,
+                          int C, int H, int W, void* stream) {
+  SST_REQUIRE(g && pre && out && partial && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0, "sst_clamp_bwd: bad argument");
+  const int nb = sst_clamp_bwd_blocks(B, H, W);
+  clamp_bwd_kernel<<<nb, NT, 0, sst_stream(stream)>>>(g, pre, out, partial, B, C, H, W);
+  SST_LAUNCH_CHECK("clamp_bwd_kernel");
+  if (dbias) {
+    colsum_finalize_kernel<<<1, 64, 0, sst_stream(stream)>>>(partial, dbias, nb, C, accumulate);
+    SST_LAUNCH_CHECK("colsum_finalize_kernel");
+  }
+  return SST_OK;
+}
+
+SST_API int sst_pixel_loss_blocks(int64_t n) { return grid_for(n / 4 + 1); }
+
+SST_API int sst_pixel_loss_fwd(const float* x, const float* gt, float* loss, float* partials, unsigned* counter, int64_t n,
+                               int mode, void* stream) {
+  SST_REQUIRE(x && gt && loss && partials && counter && n > 0 && (mode == 0 || mode == 1), "sst_pixel_loss_fwd: bad argument");
+  pixel_loss_fwd_kernel<<<sst_pixel_loss_blocks(n), NT, 0, sst_stream(stream)>>>(x, gt, loss, partials, counter, n, mode);
+  SST_LAUNCH_CHECK("pixel_loss_fwd_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_pixel_loss_bwd(const float* x, const float* gt, float* dx, const float* scale_dev, float scale_host,
+                               int accumulate, int64_t n, int mode, void* stream) {
+  SST_REQUIRE(x && gt && dx && n > 0 && (mode == 0 || mode == 1), "sst_pixel_loss_bwd: bad argument");
+  pixel_loss_bwd_kernel<<<grid_for(n), NT, 0, sst_stream(stream)>>>(x, gt, dx, scale_dev, scale_host, accumulate, n, mode);
+  SST_LAUNCH_CHECK("pixel_loss_bwd_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_bce_logits(const float* logits, float target, float* loss, float* dlogits, const float* scale_dev,
+                           float scale_host, int n, void* stream) {
+  SST_REQUIRE(logits && n > 0 && (loss || dlogits), "sst_bce_logits: bad argument");
+  bce_fwd_bwd_kernel<<<1, NT, 0, sst_stream(stream)>>>(logits, target, loss, dlogits, scale_dev, scale_host, n);
+  SST_LAUNCH_CHECK("bce_fwd_bwd_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_weighted_sum(const float* const* terms, const float* weights, int n, float* out, float* weighted,
+                             void* stream) {
+  SST_REQUIRE(terms && weights && out && n > 0 && n <= 8, "sst_weighted_sum: 1..8 terms");
+  ScalarPtrs sp;
+  for (int i = 0; i < n; ++i) {
+    SST_REQUIRE(terms[i], "sst_weighted_sum: null term");
+    sp.p[i] = terms[i];
+    sp.w[i] = weights[i];
+  }
+  weighted_sum_kernel<<<1, 64, 0, sst_stream(stream)>>>(sp, n, out, weighted);
+  SST_LAUNCH_CHECK("weighted_sum_kernel");
+  return SST_OK;
+}

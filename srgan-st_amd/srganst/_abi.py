@@ -36,9 +36,17 @@ SIGNATURES = {
     "sst_bwd_reduce_blocks": (c_int, [c_int64, c_int]),
     "sst_bwd_reduce": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P]),
     "sst_bwd_finalize": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P]),
-    "sst_bwd_apply": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int64, c_int, P]),
+    "sst_bwd_apply": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     "sst_add": (c_int, [P, P, P, c_int64, P]),
     "sst_slab_reduce": (c_int, [P, P, c_int, c_int64, c_int, P]),
+    "sst_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_clamp_bwd_blocks": (c_int, [c_int, c_int, c_int]),
+    "sst_clamp_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_pixel_loss_blocks": (c_int, [c_int64]),
+    "sst_pixel_loss_fwd": (c_int, [P, P, P, P, P, c_int64, c_int, P]),
+    "sst_pixel_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int64, c_int, P]),
+    "sst_bce_logits": (c_int, [P, c_float, P, P, P, c_float, c_int, P]),
+    "sst_weighted_sum": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, P, P, P]),
 }
 
 _lib = None

@@ -1,0 +1,118 @@
+"""Config surface - attribute-compatible with reference config.py:15-139 (same tree, same
+defaults, same add_g_criterion/remove_g_criterion/get_all_params), plus DIST.* / KERNEL.* knobs.
+
+Differences, all additive:
+  * criterion objects default to the HIP-path modules of srganst.loss (same call protocol
+    ``criterion(sr, gt) -> 0-dim``); 'Adversarial' keeps its special (D(sr), real_label) call;
+  * class-level dicts are copied per instance (the reference shares them between instances,
+    config.py:19,33,45,57 - an accident, not an interface).
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+
+
+class dotdict(dict):
+    """dot.notation access to dictionary attributes (reference config.py:3-13)."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+    __delattr__ = dict.__delitem__
+    __dir__ = dict.keys
+    __repr__ = dict.__repr__
+
+
+class Config:
+    def __init__(self):
+        from . import loss as L
+
+        self.DEVICE = "cuda:0" if torch.cuda.is_available() else "cpu"
+
+        self.EXP = dotdict()
+        self.EXP.USER = "s204163"
+        self.EXP.NAME = "experiment-name"
+        self.EXP.START_EPOCH = 0
+        self.EXP.N_EPOCHS = 40
+        self.EXP.LABEL_SMOOTHING = 0.1
+
+        self.LOG_TRAIN_PERIOD = 100
+        self.LOG_VALIDATION_PERIOD = 1
+        self.D_CHECKPOINT_INTERVAL = 100
+        self.G_CHECKPOINT_INTERVAL = 100
+
+        self.DATA = dotdict()
+        self.DATA.TRAIN_GT_IMAGES_DIR = f"/work3/{self.EXP.USER}/data/train"
+        self.DATA.TEST_SET = "Set5"
+        self.DATA.TEST_GT_IMAGES_DIR = f"/work3/{self.EXP.USER}/data/{self.DATA.TEST_SET}/GTmod12"
+        self.DATA.TEST_LR_IMAGES_DIR = f"/work3/{self.EXP.USER}/data/{self.DATA.TEST_SET}/LRbicx4"
+        self.DATA.TEST_SR_IMAGES_DIR = "results/_test"
+        self.DATA.SEED = 0
+        self.DATA.UPSCALE_FACTOR = 4
+        self.DATA.BATCH_SIZE = 16
+        self.DATA.GT_IMAGE_SIZE = 96
+
+        self.MODEL = dotdict()
+        self.MODEL.G_CONTINUE_FROM_WARMUP = False
+        self.MODEL.G_WARMUP_WEIGHTS = ""
+        self.MODEL.D_CONTINUE_FROM_WARMUP = False
+        self.MODEL.D_WARMUP_WEIGHTS = ""
+        self.MODEL.G_IN_CHANNEL = 3
+        self.MODEL.G_OUT_CHANNEL = 3
+        self.MODEL.G_N_CHANNEL = 64
+        self.MODEL.G_N_RCB = 16
+
+        self.MODEL.G_LOSS = dotdict()
+        self.MODEL.G_LOSS.VGG19_LAYERS = {"features.17": 1 / 8, "features.26": 1 / 4, "features.35": 1 / 2}
+        self.MODEL.G_LOSS.DISC_FEATURES_LOSS_LAYERS = {"features.4": 1 / 4, "features.10": 1 / 2}
+        self.MODEL.G_LOSS.CRITERIONS = {"Adversarial": L.BCEWithLogitsLoss()}
+        self.MODEL.G_LOSS.CRITERION_WEIGHTS = {
+            "Adversarial": 0.001, "ContentVGG": 1.0, "ContentDiscriminator": 2000.0, "Pixel": 1.0,
+            "BestBuddy": 50.0, "Gram": 500.0, "PatchwiseST": 100.0, "ST": 1 / 3,
+        }
+        self.MODEL.G_LOSS.WARMUP_CRITERIONS = {"Pixel": L.MSELoss()}
+        self.MODEL.G_LOSS.WARMUP_WEIGHTS = {"Pixel": 1.0}
+        self.MODEL.D_IN_CHANNEL = 3
+        self.MODEL.D_OUT_CHANNEL = 1
+        self.MODEL.D_N_CHANNEL = 64
+
+        self.SOLVER = dotdict()
+        self.SOLVER.D_UPDATE_INTERVAL = 100
+        self.SOLVER.D_OPTIMIZER = "Adam"
+        self.SOLVER.D_BASE_LR = 1e-4
+        self.SOLVER.D_BETA1 = 0.9
+        self.SOLVER.D_BETA2 = 0.999
+        self.SOLVER.D_WEIGHT_DECAY = 0
+        self.SOLVER.D_EPS = 1e-4
+        self.SOLVER.G_OPTIMIZER = "Adam"
+        self.SOLVER.G_BASE_LR = 1e-4
+        self.SOLVER.G_BETA1 = 0.9
+        self.SOLVER.G_BETA2 = 0.999
+        self.SOLVER.G_WEIGHT_DECAY = 0
+        self.SOLVER.G_EPS = 1e-4
+
+        self.SCHEDULER = dotdict()
+        self.SCHEDULER.STEP_SIZE = self.EXP.N_EPOCHS // 2
+        self.SCHEDULER.GAMMA = 0.5
+
+        # --- additions (not in the reference) ---
+        self.DIST = dotdict()
+        self.DIST.BACKEND = "nccl"          # RCCL on ROCm; "gloo" in the CPU tests
+        self.DIST.BUCKET_D = True           # D grads in two buckets (features / classifier)
+        self.KERNEL = dotdict()
+        self.KERNEL.USE_GRAPH = True        # capture the train step into a hipGraph
+        self.KERNEL.SYNC_LOSS_EVERY_STEP = False  # reference does .item() per criterion per step (train.py:141)
+
+    def add_g_criterion(self, name: str, value, weight: float = 1.0) -> None:
+        self.MODEL.G_LOSS.CRITERIONS[name] = value
+        self.MODEL.G_LOSS.CRITERION_WEIGHTS[name] = weight
+
+    def remove_g_criterion(self, name: str) -> None:
+        if name in self.MODEL.G_LOSS.CRITERIONS:
+            del self.MODEL.G_LOSS.CRITERIONS[name]
+            del self.MODEL.G_LOSS.CRITERION_WEIGHTS[name]
+
+    def get_all_params(self) -> str:
+        params = [getattr(self, attr) for attr in dir(self)
+                  if not callable(getattr(self, attr)) and not attr.startswith("__")]
+        return str(params)

@@ -66,3 +66,86 @@ class StructureTensorLoss(nn.Module):
 
     def __repr__(self):
         return f"StructureTensorLoss(sigma={self.sigma}, rho={self.rho}, normalize={self.normalize})"
+
+
+# ------------------------------------------------------------------------------------------------
+class _PixelLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gt, mode, ws):
+        from . import ops
+        if x.shape != gt.shape or x.dtype != torch.float32:
+            raise _abi.HipPathError("pixel loss: fp32 tensors of equal shape")
+        x, gt = x.contiguous(), gt.contiguous()
+        ctx.save_for_backward(x, gt)
+        ctx.mode = mode
+        return ops.pixel_loss_fwd(x, gt, mode, ws)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import ops
+        x, gt = ctx.saved_tensors
+        return ops.pixel_loss_bwd(x, gt, ctx.mode, scale_dev=grad_out.contiguous()), None, None, None
+
+
+class MSELoss(nn.Module):
+    """nn.MSELoss() of reference config.py:88-90 on the HIP path."""
+
+    def __init__(self):
+        super().__init__()
+        self._ws = {}
+
+    def forward(self, x, gt):
+        return _PixelLossFn.apply(x, gt, 0, self._ws)
+
+
+class L1Loss(nn.Module):
+    """Pixel-L1 variant named by BASELINE.json configs[0] (one-line config change in the reference)."""
+
+    def __init__(self):
+        super().__init__()
+        self._ws = {}
+
+    def forward(self, x, gt):
+        return _PixelLossFn.apply(x, gt, 1, self._ws)
+
+
+class _BceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target_value):
+        from . import ops
+        logits = logits.contiguous()
+        ctx.save_for_backward(logits)
+        ctx.t = target_value
+        loss, _ = ops.bce_logits(logits, target_value, want_loss=True)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import ops
+        (logits,) = ctx.saved_tensors
+        _, dl = ops.bce_logits(logits, ctx.t, want_loss=False, want_grad=True, scale_dev=grad_out.contiguous())
+        return dl, None
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """nn.BCEWithLogitsLoss() of reference config.py:71-73 / train.py:59.  The reference always calls it
+    with a constant-filled label tensor (train.py:113-114: 0.9 or 0); the label value is read once on the
+    host when the label tensor is first seen (cached by identity), so there is no per-step sync."""
+
+    def __init__(self):
+        super().__init__()
+        self._label_cache = {}
+
+    def forward(self, logits, label):
+        if isinstance(label, (int, float)):
+            t = float(label)
+        else:
+            key = (label.data_ptr(), label._version, tuple(label.shape))
+            t = self._label_cache.get(key)
+            if t is None:
+                t = float(label.flatten()[0].item())
+                if not bool((label == t).all().item()):
+                    raise _abi.HipPathError("BCEWithLogitsLoss (HIP path): label tensor must be constant-filled "
+                                            "(reference train.py:113-114 uses full([B,1], 0.9) / zeros)")
+                self._label_cache = {key: t}
+        return _BceFn.apply(logits, t)

@@ -125,11 +125,20 @@ def bwd_finalize(partial, n, mean=None, rstd=None, gamma=None, dgamma=None, dbet
     return cA, cB, cC
 
 
-def bwd_apply(g, y, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, cA=None, cB=None, cC=None):
+def bwd_apply(g, y, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, cA=None, cB=None, cC=None,
+              unshuffle=False):
+    """dy = cA*gz + cB*y + cC (BN input grad) or gz (activation grad only).  unshuffle: y is [B,2h,2w,C] and dy
+    is stored as the pre-PixelShuffle tensor [B,h,w,4C]."""
     C = y.shape[-1]
-    dy = torch.empty_like(y)
+    uh = uw = 0
+    if unshuffle:
+        B, uh, uw, _ = y.shape
+        dy = _f32(B, uh // 2, uw // 2, 4 * C, like=y)
+    else:
+        dy = torch.empty_like(y)
     check(_abi.lib().sst_bwd_apply(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
-                                   ptr(cA), ptr(cB), ptr(cC), ptr(dy), y.numel() // C, C, stream_ptr()), "sst_bwd_apply")
+                                   ptr(cA), ptr(cB), ptr(cC), ptr(dy), y.numel() // C, C, uh, uw, stream_ptr()),
+          "sst_bwd_apply")
     return dy
 
 
@@ -137,3 +146,55 @@ def add(a, b):
     out = torch.empty_like(a)
     check(_abi.lib().sst_add(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr()), "sst_add")
     return out
+
+
+def transpose(x, to_nchw: bool):
+    """NHWC [B,H,W,C] -> NCHW [B,C,H,W] (to_nchw) or the inverse."""
+    if to_nchw:
+        B, H, W, C = x.shape
+        out = _f32(B, C, H, W, like=x)
+    else:
+        B, C, H, W = x.shape
+        out = _f32(B, H, W, C, like=x)
+    check(_abi.lib().sst_transpose(ptr(x), ptr(out), B, C, H, W, int(to_nchw), stream_ptr()), "sst_transpose")
+    return out
+
+
+def clamp_bwd(g, pre, dbias=None, accumulate=False):
+    """g, pre NCHW [B,C<=4,H,W] -> masked gradient NHWC [B,H,W,C]; dbias (+)= its column sums."""
+    B, C, H, W = g.shape
+    out = _f32(B, H, W, C, like=g)
+    partial = _f32(_abi.lib().sst_clamp_bwd_blocks(B, H, W) * C, like=g)
+    check(_abi.lib().sst_clamp_bwd(ptr(g), ptr(pre), ptr(out), ptr(partial), ptr(dbias), int(accumulate), B, C, H, W,
+                                   stream_ptr()), "sst_clamp_bwd")
+    return out
+
+
+def pixel_loss_fwd(x, gt, mode, ws):
+    n = x.numel()
+    key = (x.device, n)
+    if ws.get("key") != key:
+        ws["key"] = key
+        ws["partials"] = _f32(_abi.lib().sst_pixel_loss_blocks(n), like=x)
+        ws["counter"] = torch.zeros(1, device=x.device, dtype=torch.int32)
+    loss = _f32((), like=x)
+    check(_abi.lib().sst_pixel_loss_fwd(ptr(x), ptr(gt), ptr(loss), ptr(ws["partials"]), ptr(ws["counter"]), n, mode,
+                                        stream_ptr()), "sst_pixel_loss_fwd")
+    return loss
+
+
+def pixel_loss_bwd(x, gt, mode, scale_dev=None, scale_host=1.0, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty_like(x)
+        accumulate = False
+    check(_abi.lib().sst_pixel_loss_bwd(ptr(x), ptr(gt), ptr(out), ptr(scale_dev), float(scale_host), int(accumulate), x.numel(),
+                                        mode, stream_ptr()), "sst_pixel_loss_bwd")
+    return out
+
+
+def bce_logits(logits, target, want_loss=True, want_grad=False, scale_dev=None, scale_host=1.0):
+    loss = _f32((), like=logits) if want_loss else None
+    dl = torch.empty_like(logits) if want_grad else None
+    check(_abi.lib().sst_bce_logits(ptr(logits), float(target), ptr(loss), ptr(dl), ptr(scale_dev), float(scale_host),
+                                    logits.numel(), stream_ptr()), "sst_bce_logits")
+    return loss, dl
