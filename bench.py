@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the SRGAN-ST training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload srresnet|srgan]
+
+N=1 workload (default): BASELINE.json configs[1] - SRResNet x4, 96 px HR crops, B=16 per GPU,
+pixel(MSE) + structure-tensor/3 loss, one full optimisation step (G fwd, losses, G bwd, Adam).
+`--workload srgan` = configs[2] without the VGG content term (G + D + adversarial + pixel + ST, D updated every step).
+Prints ONE JSON line (rank 0).  Inputs are synthetic DIV2K-shaped tensors already resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "srgan-st_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+G_FWD_MAC_PER_IMG = 1277.67e6      # BASELINE.md section 2 (HR 96)
+D_FWD_MAC_PER_IMG = 884.15e6
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(B, hr, device, seed):
+    """HR crops on the 1/255 grid + x1/4 LR (antialiased bicubic, re-quantised like dataset.py:27-28)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    gt = torch.randint(0, 256, (B, 3, hr, hr), generator=g, dtype=torch.uint8).float() / 255.0
+    lr = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True, align_corners=False)
+    lr = torch.round(lr * 255.0) / 255.0
+    return gt.to(device), lr.to(device)
+
+
+def build_engine(workload, device, use_graph, hr):
+    from srganst.config import Config
+    from srganst.engine import TrainEngine, WarmupEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+    cfg = Config()
+    cfg.DEVICE = str(device)
+    cfg.DATA.GT_IMAGE_SIZE = hr
+    torch.manual_seed(cfg.DATA.SEED)
+    if workload == "srresnet":
+        G = Generator(cfg).to(device).train()
+        crits = {"Pixel": MSELoss(), "ST": StructureTensorLoss()}
+        w = {"Pixel": 1.0, "ST": 1.0 / 3.0}
+        return WarmupEngine(cfg, G, crits, w, use_graph=use_graph), cfg
+    D = Discriminator(cfg).to(device).train()
+    G = Generator(cfg).to(device).train()
+    cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+    cfg.add_g_criterion("ST", StructureTensorLoss(), 1.0 / 3.0)
+    cfg.SOLVER.D_UPDATE_INTERVAL = 1
+    return TrainEngine(cfg, G, D, use_graph=use_graph), cfg
+
+
+def kernel_roofline(workload, device, hr, B):
+    """Per-launch timing (HIP events on the launch stream) of the MFMA kernels over two eager steps."""
+    from srganst import ops
+    eng, _ = build_engine(workload, device, use_graph=False, hr=hr)
+    gt, lr = synth_batch(B, hr, device, 1)
+    eng.step(gt, lr)
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    for _ in range(3):
+        eng.step(gt, lr)
+    torch.cuda.synchronize()
+    agg = {}
+    for name, flops, e0, e1 in ops.PROFILE:
+        a = agg.setdefault(name, [0.0, 0.0, 0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    ops.PROFILE = None
+    rows = {k: {"launches_per_step": v[2] // 3, "avg_us": v[1] / v[2] * 1e6, "tflops": v[0] / v[1] / 1e12,
+                "time_share_ms_per_step": v[1] / 3 * 1e3} for k, v in agg.items()}
+    dom = max(agg, key=lambda k: agg[k][1])
+    a = agg[dom]
+    roof = {"bound": "mfma", "kernel": dom, "achieved": a[0] / a[1] / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": a[0] / a[1] / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "avg_launch_us": a[1] / a[2] * 1e6, "flop_per_launch": a[0] / a[2], "kernels": rows}
+    return roof
+
+
+def cpu_baseline(workload, B, hr, budget_s=20.0):
+    """The CPU oracle (plain-torch restatement of the reference step) timed on the host cores: a bounded sample."""
+    from oracle import model as om
+    from oracle import steps as osteps
+    torch.manual_seed(0)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))     # the 1-GPU box's CPU share is 16 cores; oversubscribing it is far slower
+    torch.set_num_threads(threads)
+    if workload == "srresnet":
+        tr = osteps.OracleTrainer(om.init_generator_state(), criterions=(("Pixel", 1.0), ("ST", 1.0 / 3.0)))
+        fn = tr.warmup_step
+    else:
+        d0 = om.init_discriminator_state(image_size=hr)
+        tr = osteps.OracleTrainer(om.init_generator_state(), d0, criterions=(("Adversarial", 0.001), ("Pixel", 1.0), ("ST", 1.0 / 3.0)),
+                                  d_update_interval=1)
+        fn = tr.train_step
+    gt, lr = synth_batch(B, hr, "cpu", 1)
+    fn(gt, lr)                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn(gt, lr)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 40:
+            break
+    return {"value": B * n / el, "unit": "HR images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of the same B={B} {hr}px step through oracle/ (torch CPU eager, {threads} threads), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="srresnet", choices=["srresnet", "srgan"])
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--hr", type=int, default=96)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from srganst import _abi, dist as sdist
+    _abi.lib()                                    # fail loudly if the HIP extension is missing
+    rank, local, world = sdist.init_from_env("nccl")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    eng, cfg = build_engine(args.workload, device, use_graph=not args.no_graph, hr=args.hr)
+    if world > 1:
+        sdist.broadcast_module(eng.G)
+        if hasattr(eng, "D"):
+            sdist.broadcast_module(eng.D)
+    B = args.batch
+    gt, lr = synth_batch(B, args.hr, device, seed=100 + rank)      # distinct shard per rank, resident in HBM
+
+    for _ in range(max(args.warmup, 4)):                            # >= 4: eager warm-ups + graph capture happen here
+        eng.step(gt, lr)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(gt, lr)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    losses = {k: float(v) for k, v in eng.loss_values.items()}
+
+    out = None
+    if rank == 0:
+        ms = el / args.steps * 1e3
+        imgs = B * world * args.steps / el
+        if args.workload == "srresnet":
+            flop_img = 3 * 2 * G_FWD_MAC_PER_IMG
+            wl = "srresnet_x4_hr96_b16_mse+st (BASELINE configs[1])"
+        else:
+            flop_img = 2 * (3 * G_FWD_MAC_PER_IMG + 2 * D_FWD_MAC_PER_IMG + 6 * D_FWD_MAC_PER_IMG)
+            wl = "srgan_x4_hr96_b16_adv+mse+st_D-every-step (BASELINE configs[2] minus VGG content)"
+        if args.hr != 96:
+            wl = wl.replace("hr96", f"hr{args.hr}")
+            flop_img *= (args.hr / 96.0) ** 2
+        out = {"metric": "HR images/sec (96px x4, B=16/GPU) training step", "value": imgs, "unit": "HR images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": wl, "global_batch": B * world, "hr": args.hr, "lr": args.hr // 4,
+                          "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                          "step_tflops": flop_img * imgs / 1e12, "losses_last_step": losses}}
+    if rank == 0 and world == 1 and not args.no_roofline:
+        out["roofline"] = kernel_roofline(args.workload, device, args.hr, B)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, B, args.hr)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

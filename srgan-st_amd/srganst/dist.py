@@ -1,0 +1,82 @@
+"""Data parallelism: one process per GPU, gradient averaging with RCCL over xGMI.
+
+The reference has no distributed code at all; this is the subsystem the
+build adds.  Semantics (standard DDP): every rank runs the same step on its own [B] batch,
+BatchNorm statistics stay rank-local, parameter gradients are averaged over ranks before the
+optimizer step, so parameters stay bit-identical across ranks.
+
+Payload: G = 1,547,350 fp32 (6.2 MB) after every G backward; D = 23,563,649 fp32 (94 MB) after
+every D backward.  xGMI is point-to-point, so collectives are per-link bound: few, large,
+flat buffers - G goes out as ONE all-reduce; D as two buckets (features 4.7 M / classifier
+18.9 M floats) so the first can start while the second is flattened.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as td
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """torchrun-style env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*) -> (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not td.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            td.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def world_size(pg=None) -> int:
+    return td.get_world_size(pg) if td.is_available() and td.is_initialized() else 1
+
+
+def bucket_slices(numels, buckets: int):
+    """Split a parameter list into `buckets` contiguous groups of roughly equal payload (in list order)."""
+    total = sum(numels)
+    out, start, acc, target = [], 0, 0, total / max(buckets, 1)
+    for i, n in enumerate(numels):
+        acc += n
+        if acc >= target * (len(out) + 1) and len(out) < buckets - 1:
+            out.append((start, i + 1))
+            start = i + 1
+    out.append((start, len(numels)))
+    return [s for s in out if s[0] < s[1]]
+
+
+def allreduce_grads(params, pg=None, buckets: int = 1) -> None:
+    """p.grad <- mean over ranks of p.grad, for every parameter that has a gradient."""
+    world = world_size(pg)
+    if world == 1:
+        return
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return
+    handles = []
+    for a, b in bucket_slices([p.grad.numel() for p in ps], buckets):
+        grads = [p.grad for p in ps[a:b]]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        h = td.all_reduce(flat, op=td.ReduceOp.SUM, group=pg, async_op=True)
+        handles.append((h, flat, grads))
+    for h, flat, grads in handles:
+        h.wait()
+        flat.mul_(1.0 / world)
+        for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(f)
+
+
+def broadcast_module(module, src: int = 0, pg=None) -> None:
+    """Make parameters and buffers identical on every rank (rank `src` wins)."""
+    if world_size(pg) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        td.broadcast(t.data, src=src, group=pg)

@@ -1,0 +1,215 @@
+"""Step engines: the inner loops of reference warmup.py:74-96 and train.py:116-164 as objects.
+
+    WarmupEngine.step(gt, lr)   G fwd -> sum_w criterion(sr,gt)*w -> bwd -> [RCCL all-reduce] -> Adam
+    TrainEngine.step(gt, lr)    G update (D frozen but in train mode: its BN stats move, train.py:110,136),
+                                then D update every D_UPDATE_INTERVAL-th batch on gt and sr.detach()
+
+Same semantics as the reference step by step; what differs is execution:
+  * the whole step (kernels of libsrganst.so + optimizer) is captured once into a hipGraph and
+    replayed (no tracing compiler; the reference uses torch.compile, train.py:56);
+  * loss values stay on the device; ``.item()`` happens only when the caller asks (the reference
+    syncs per criterion per step, train.py:141);
+  * data parallel: one process per GPU, gradients averaged with a single flat RCCL all-reduce
+    (srganst.dist) between backward and the optimizer step.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from . import dist as sdist
+
+
+def make_adam(params, lr, betas, eps, weight_decay, capturable):
+    # torch.optim.Adam is third-party arithmetic the reference uses as-is (train.py:62-75); fused=True runs the
+    # same update in a handful of multi-tensor launches and is graph-capturable.
+    return torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True,
+                            capturable=capturable)
+
+
+class _GraphedStep:
+    """Capture ``fn()`` (which reads the static input buffers) into a hipGraph after a few eager warm-up calls."""
+
+    def __init__(self, fn, warmup_calls=2, enabled=True):
+        self.fn = fn
+        self.graph = None
+        self.enabled = enabled
+        self.calls = 0
+        self.warmup_calls = warmup_calls
+        self.out = None
+
+    def __call__(self):
+        if not self.enabled:
+            return self.fn()
+        if self.graph is None:
+            if self.calls < self.warmup_calls:
+                self.calls += 1
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    out = self.fn()
+                torch.cuda.current_stream().wait_stream(s)
+                return out
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.out = self.fn()
+            self.graph = g
+        self.graph.replay()
+        return self.out
+
+
+class WarmupEngine:
+    """reference warmup.py:14-96 without the data loader / logging / validation around the step."""
+
+    def __init__(self, config, generator, criterions=None, weights=None, use_graph=None, process_group=None):
+        self.config = config
+        self.G = generator
+        self.criterions = criterions if criterions is not None else config.MODEL.G_LOSS.WARMUP_CRITERIONS
+        self.weights = weights if weights is not None else config.MODEL.G_LOSS.WARMUP_WEIGHTS
+        self.pg = process_group
+        self.world = sdist.world_size(process_group)
+        use_graph = config.KERNEL.USE_GRAPH if use_graph is None else use_graph
+        self.opt = make_adam(self.G.parameters(), config.SOLVER.G_BASE_LR, (config.SOLVER.G_BETA1, config.SOLVER.G_BETA2),
+                             config.SOLVER.G_EPS, config.SOLVER.G_WEIGHT_DECAY, capturable=use_graph)
+        self.gt = self.lr = None
+        self.loss_values = OrderedDict()
+        self.sr = None
+        if self.world > 1:      # collective stays outside the graph: [fwd+bwd graph] -> all-reduce -> [optimizer]
+            self._fb = _GraphedStep(self._fwd_bwd, enabled=use_graph)
+            self._op = _GraphedStep(self._opt_step, enabled=use_graph)
+        else:
+            self._fb = _GraphedStep(self._full_step, enabled=use_graph)
+            self._op = None
+
+    # -- pieces
+    def _fwd_bwd(self):
+        self.opt.zero_grad(set_to_none=True)
+        sr = self.G(self.lr)
+        total = None
+        vals = OrderedDict()
+        for name, crit in self.criterions.items():
+            l = crit(sr, self.gt) * self.weights[name]
+            vals[name] = l.detach()
+            total = l if total is None else total + l
+        total.backward()
+        self.sr = sr.detach()
+        self.loss_values = vals
+        return vals
+
+    def _opt_step(self):
+        self.opt.step()
+
+    def _full_step(self):
+        vals = self._fwd_bwd()
+        self.opt.step()
+        return vals
+
+    def step(self, gt, lr):
+        """One optimisation step on the batch (gt [B,3,H,W], lr [B,3,H/4,W/4], device tensors)."""
+        if self.gt is None:
+            self.gt, self.lr = gt.clone(), lr.clone()
+        else:
+            self.gt.copy_(gt, non_blocking=True)
+            self.lr.copy_(lr, non_blocking=True)
+        self._fb()
+        if self.world > 1:
+            sdist.allreduce_grads(self.G.parameters(), self.pg)
+            self._op()
+        return self.loss_values
+
+
+class TrainEngine:
+    """reference train.py:16-164 without loaders / logging / validation around the step."""
+
+    def __init__(self, config, generator, discriminator, use_graph=None, process_group=None):
+        from .loss import BCEWithLogitsLoss
+        self.config = config
+        self.G, self.D = generator, discriminator
+        self.pg = process_group
+        self.world = sdist.world_size(process_group)
+        use_graph = config.KERNEL.USE_GRAPH if use_graph is None else use_graph
+        s = config.SOLVER
+        self.g_opt = make_adam(self.G.parameters(), s.G_BASE_LR, (s.G_BETA1, s.G_BETA2), s.G_EPS, s.G_WEIGHT_DECAY, use_graph)
+        self.d_opt = make_adam(self.D.parameters(), s.D_BASE_LR, (s.D_BETA1, s.D_BETA2), s.D_EPS, s.D_WEIGHT_DECAY, use_graph)
+        self.adv = BCEWithLogitsLoss()                      # train.py:59
+        self.real = 1.0 - config.EXP.LABEL_SMOOTHING        # train.py:113
+        self.fake = 0.0                                     # train.py:114
+        self.batch_num = 0
+        self.gt = self.lr = self.sr = None
+        self.loss_values = OrderedDict()
+        self.d_loss = self.pred_gt = self.pred_sr = None
+        g = use_graph
+        if self.world > 1:
+            self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g), _GraphedStep(self.g_opt.step, enabled=g)
+            self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g), _GraphedStep(self.d_opt.step, enabled=g)
+        else:
+            self._g_fb, self._g_op = _GraphedStep(self._g_full, enabled=g), None
+            self._d_fb, self._d_op = _GraphedStep(self._d_full, enabled=g), None
+
+    # -- generator half: train.py:125-144
+    def _g_fwd_bwd(self):
+        cfg = self.config
+        for p in self.D.parameters():
+            p.requires_grad = False
+        self.g_opt.zero_grad(set_to_none=True)
+        sr = self.G(self.lr)
+        total = None
+        vals = OrderedDict()
+        for name, crit in cfg.MODEL.G_LOSS.CRITERIONS.items():
+            w = cfg.MODEL.G_LOSS.CRITERION_WEIGHTS[name]
+            if name == "Adversarial":
+                l = crit(self.D(sr), self.real)
+            else:
+                l = crit(sr, self.gt)
+            l = l * w
+            vals[name] = l.detach()
+            total = l if total is None else total + l
+        total.backward()
+        self.sr = sr.detach()
+        self.loss_values = vals
+        return vals
+
+    def _g_full(self):
+        v = self._g_fwd_bwd()
+        self.g_opt.step()
+        return v
+
+    # -- discriminator half: train.py:149-164
+    def _d_fwd_bwd(self):
+        for p in self.D.parameters():
+            p.requires_grad = True
+        self.d_opt.zero_grad(set_to_none=True)
+        pred_gt = self.D(self.gt)
+        loss_real = self.adv(pred_gt, self.real)
+        pred_sr = self.D(self.sr.detach().clone())
+        loss_fake = self.adv(pred_sr, self.fake)
+        d_loss = loss_real + loss_fake
+        d_loss.backward()
+        self.d_loss, self.pred_gt, self.pred_sr = d_loss.detach(), pred_gt.detach(), pred_sr.detach()
+        return self.d_loss
+
+    def _d_full(self):
+        v = self._d_fwd_bwd()
+        self.d_opt.step()
+        return v
+
+    def step(self, gt, lr):
+        if self.gt is None:
+            self.gt, self.lr = gt.clone(), lr.clone()
+        else:
+            self.gt.copy_(gt, non_blocking=True)
+            self.lr.copy_(lr, non_blocking=True)
+        self._g_fb()
+        if self.world > 1:
+            sdist.allreduce_grads(self.G.parameters(), self.pg)
+            self._g_op()
+        did_d = False
+        if self.batch_num % self.config.SOLVER.D_UPDATE_INTERVAL == 0:
+            self._d_fb()
+            if self.world > 1:
+                sdist.allreduce_grads(self.D.parameters(), self.pg, buckets=2 if self.config.DIST.BUCKET_D else 1)
+                self._d_op()
+            did_d = True
+        self.batch_num += 1
+        return self.loss_values, (self.d_loss if did_d else None)

@@ -16,6 +16,25 @@ ACT_NONE, ACT_SLOPE = 0, 1
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 
+# --- optional per-launch timing of the MFMA kernels (bench.py roofline leg): list of (kernel, flops, ev0, ev1)
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, name, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((name, flops, e0, e1))
+
+
 def _f32(*shape, like):
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
@@ -56,9 +75,11 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
         mt = _abi.lib().sst_conv_mtiles(B, ho, wo)
         stats = _f32(mt, 2, cout, like=x)
         cnt = _f32(mt, like=x)
+    e0 = _prof_begin()
     check(_abi.lib().sst_conv_fwd(ptr(x), ptr(wp), ptr(y), ptr(y_pre), ptr(bias), ptr(in_scale), ptr(in_shift),
                                   ptr(in_slope), float(in_slope_const), int(in_act), ptr(residual), ptr(stats), ptr(cnt),
                                   int(out_mode), B, H, W, cin, cout, ksize, stride, stream_ptr()), "sst_conv_fwd")
+    _prof_end(e0, f"conv_fwd_kernel<{ksize},{stride}>", 2.0 * B * ho * wo * cout * cin * ksize * ksize)
     return y, y_pre, stats, cnt
 
 
@@ -71,9 +92,11 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
     assert tuple(dy.shape) == (B, ho, wo, cout) and tuple(dw_out.shape) == (cout, cin, ksize, ksize)
     nch = _abi.lib().sst_conv_wgrad_chunks(B, ho, wo, cin, cout, ksize)
     slab = _f32(nch * ksize * ksize * cout * cin, like=x)
+    e0 = _prof_begin()
     check(_abi.lib().sst_conv_wgrad(ptr(x), ptr(dy), ptr(slab), ptr(dw_out), ptr(in_scale), ptr(in_shift), ptr(in_slope),
                                     float(in_slope_const), int(in_act), B, H, W, cin, cout, stride, ksize,
                                     int(accumulate), stream_ptr()), "sst_conv_wgrad")
+    _prof_end(e0, "conv_wgrad_kernel+reduce", 2.0 * B * ho * wo * cout * cin * ksize * ksize)
     return dw_out
 
 
