@@ -57,6 +57,12 @@ int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, cons
                    const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
                    int B, int H, int W, int Cin, int Cout, int stride, int ksize, int accumulate,
                    void* stream);
+/* data-gradient of a 3x3 / stride-2 / pad-1 conv (Discriminator.features model.py:35,42,49,56): the input-gradient
+ * pixels are split into 4 parity classes, each a dense 1x1 / 1x2 / 2x1 / 2x2 correlation over dy. */
+int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin);
+int sst_conv_s2_dgrad_pack(const float* w, float* wp, int Cout, int Cin, void* stream);
+int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout,
+                      void* stream);
 
 /* ---- BatchNorm (train mode) + elementwise glue, tensors viewed as [R rows, C channels] -----------
  * nn.BatchNorm2d model.py:36-57,114,174,177 (eps 1e-5, momentum .1); PReLU/LeakyReLU backward;
@@ -99,6 +105,23 @@ int sst_bce_logits(const float* logits, float target, float* loss, float* dlogit
                    const float* scale_dev, float scale_host, int n, void* stream);
 int sst_weighted_sum(const float* const* terms, const float* weights, int n, float* out, float* weighted,
                      void* stream);
+
+/* ---- discriminator classifier: flatten + Linear + LeakyReLU + Linear (model.py:61-65,69-70) -------
+ * weights in the reference layout [N][K]; x [M][K], y [M][N], M <= 64.
+ * sst_linear_dgrad: nhwc_HW > 0 scatters dx from the NCHW-flatten index k=(c,hw) to NHWC [M][HW][C]. */
+int sst_linear_ksplit(int M, int N, int K);
+int sst_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* slab, int M, int N,
+                   int K, void* stream);
+int sst_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, int K, int nhwc_C,
+                     int nhwc_HW, void* stream);
+int sst_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+                     int accumulate, void* stream);
+int sst_head_fwd(const float* h, const float* w, const float* b, float* y, int M, int N, int K, float slope,
+                 void* stream);
+int sst_head_bwd(const float* h, const float* w, const float* dy, float* dh, float* dw, float* db, int M,
+                 int N, int K, float slope, int accumulate, void* stream);
+int sst_flatten_act(const float* y, const float* scale, const float* shift, float slope, int act,
+                    float* flat, int B, int HW, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -155,42 +155,62 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
 // Finalize of the above.  If mean != null (BatchNorm): writes dgamma, dbeta and the coefficients of
 //   dy = cA[c]*gz + cB[c]*y + cC[c]          (gz as defined above)
 // else (no BN: bias-only layer): writes dbias = sum gz.   dslope (scalar) += sum_c partial[2] when dslope != null.
-__global__ __launch_bounds__(NT) void bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float n,
+constexpr int FT = 1024;   // threads of the (single-workgroup) finalize kernel
+__global__ __launch_bounds__(FT) void bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float n,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, float* __restrict__ cA,
                                                           float* __restrict__ cB, float* __restrict__ cC,
                                                           float* __restrict__ dslope, int accumulate) {
-  __shared__ float red[NT / 64];
+  __shared__ float sm[3][FT];
+  __shared__ float red[FT / 64];
   float al = 0.f;
-  for (int c = threadIdx.x; c < C; c += NT) {
+  // L lanes per channel split the nblk partials; lane 0 of each channel combines them in fixed order
+  const int L = C >= FT ? 1 : FT / C;
+  for (int cbase = 0; cbase < C; cbase += FT / L) {
+    const int c = cbase + (int)threadIdx.x / L, q = threadIdx.x % L;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-      s0 += partial[(size_t)b * 3 * C + c];
-      s1 += partial[(size_t)b * 3 * C + C + c];
-      s2 += partial[(size_t)b * 3 * C + 2 * C + c];
-    }
-    al += s2;
-    if (mean) {
-      const float mu = mean[c], rs = rstd[c], ga = gamma[c];
-      const float sgh = rs * (s1 - mu * s0);   // sum gz * yhat
-      const float m1 = s0 / n, m2 = sgh / n;
-      if (accumulate) {
-        dgamma[c] += sgh;
-        dbeta[c] += s0;
-      } else {
-        dgamma[c] = sgh;
-        dbeta[c] = s0;
+    if (c < C) {
+      for (int b = q; b < nblk; b += L) {
+        s0 += partial[(size_t)b * 3 * C + c];
+        s1 += partial[(size_t)b * 3 * C + C + c];
+        s2 += partial[(size_t)b * 3 * C + 2 * C + c];
       }
-      const float a = ga * rs;
-      cA[c] = a;
-      cB[c] = -a * rs * m2;
-      cC[c] = -a * m1 + a * rs * mu * m2;
-    } else if (dbeta) {
-      if (accumulate) dbeta[c] += s0; else dbeta[c] = s0;
+    }
+    __syncthreads();
+    sm[0][threadIdx.x] = s0;
+    sm[1][threadIdx.x] = s1;
+    sm[2][threadIdx.x] = s2;
+    __syncthreads();
+    if (c < C && q == 0) {
+      s0 = s1 = s2 = 0.f;
+      for (int i = 0; i < L; ++i) {
+        s0 += sm[0][threadIdx.x + i];
+        s1 += sm[1][threadIdx.x + i];
+        s2 += sm[2][threadIdx.x + i];
+      }
+      al += s2;
+      if (mean) {
+        const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+        const float sgh = rs * (s1 - mu * s0);   // sum gz * yhat
+        const float m1 = s0 / n, m2 = sgh / n;
+        if (accumulate) {
+          dgamma[c] += sgh;
+          dbeta[c] += s0;
+        } else {
+          dgamma[c] = sgh;
+          dbeta[c] = s0;
+        }
+        const float a = ga * rs;
+        cA[c] = a;
+        cB[c] = -a * rs * m2;
+        cC[c] = -a * m1 + a * rs * mu * m2;
+      } else if (dbeta) {
+        if (accumulate) dbeta[c] += s0; else dbeta[c] = s0;
+      }
     }
   }
-  al = block_sum<NT>(al, red);
+  al = block_sum<FT>(al, red);
   if (dslope && threadIdx.x == 0) {
     if (accumulate) dslope[0] += al; else dslope[0] = al;
   }
@@ -290,9 +310,9 @@ SST_API int sst_bn_residual(const float* y, const float* scale, const float* shi
 }
 
 SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
-  // enough blocks to fill the chip, at least 32 rows each
-  int64_t nb = (R + 31) / 32;
-  if (nb > 512) nb = 512;
+  // few, fat blocks: the tensors are L2-resident and the finalize kernel walks the partials
+  int64_t nb = (R + 127) / 128;
+  if (nb > 256) nb = 256;
   return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -317,7 +337,7 @@ SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, con
                              float* dslope, int accumulate, void* stream) {
   SST_REQUIRE(partial && nblk > 0 && C > 0, "sst_bwd_finalize: bad argument");
   SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize: BN mode needs all BN pointers");
-  bwd_finalize_kernel<<<1, NT, 0, sst_stream(stream)>>>(partial, nblk, C, n, mean, rstd, gamma, dgamma, dbeta, cA, cB, cC,
+  bwd_finalize_kernel<<<1, FT, 0, sst_stream(stream)>>>(partial, nblk, C, n, mean, rstd, gamma, dgamma, dbeta, cA, cB, cC,
                                                         dslope, accumulate);
   SST_LAUNCH_CHECK("bwd_finalize_kernel");
   return SST_OK;

@@ -22,6 +22,7 @@ __host__ __device__ inline int64_t packed_index(int o, int i, int tap, int ncb, 
   return ((((int64_t)(o >> 5) * ncb + (i >> 6)) * kk + tap) * 8 + ((i & 63) >> 3)) * 256 + (((i & 7) >> 2) * 32 + (o & 31)) * 4 +
          (i & 3);
 }
+constexpr int PACK_PAD = 8 * 256;   // the K loop prefetches up to 4 chunks (1 KiB each) past a block: keep them in-bounds
 __host__ __device__ inline int64_t packed_floats(int cout, int cin, int kk) {
-  return (int64_t)((cout + 31) / 32) * ((cin + 63) / 64) * kk * 8 * 256;
+  return (int64_t)((cout + 31) / 32) * ((cin + 63) / 64) * kk * 8 * 256 + PACK_PAD;
 }

@@ -39,7 +39,11 @@ struct Conv3Args {
   float* stats_cnt;        // [n_mtiles] valid pixels per tile (written when stats != null)
   float* y_pre;            // OUT_NCHW_CLAMP: pre-clamp copy (saved for backward) or null
   int out_mode;            // OUT_*
+  int ksy, ksx, pad_y, pad_x;   // runtime tap window (<= KS x KS) and padding: KS,KS,KS/2,KS/2 for a plain conv
+  int sub_y, sub_x;        // OUT_STRIDE2: parity class of the scattered output pixels
+  int dbg;                 // ablation bits for tools/ablate_conv.py (0 in production): 1 skip staging, 2 skip K loop, 4 skip epilogue
   int B, H, W, Cin, Cout, Ho, Wo;
+  int Hy, Wy;              // OUT_STRIDE2: full size of y
 };
 
 // how the epilogue stores the [B,Ho,Wo,Cout] result
@@ -48,11 +52,12 @@ enum : int {
   OUT_SHUFFLE = 1,      // PixelShuffle(2): y[b, 2oy+i, 2ox+j, c] = out[b,oy,ox,4c+2i+j]      (model.py:160)
   OUT_NCHW_CLAMP = 2,   // y[b,co,oy,ox] = clamp(out,0,1), y_pre = out                          (model.py:148-150)
   OUT_UNSHUFFLE = 3,    // inverse of OUT_SHUFFLE: y[b, oy/2, ox/2, 4c + 2(oy&1) + (ox&1)] = out[b,oy,ox,c]
+  OUT_STRIDE2 = 4,      // y[b, 2oy+sub_y, 2ox+sub_x, c] = out (y is [B,Hy,Wy,Cout]: data-gradient of a stride-2 conv, one parity class)
 };
 
 template <int KS, int S>
 __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
-  constexpr int KK = KS * KS, PAD = KS / 2;
+  const int KK = a.ksy * a.ksx;
   constexpr int PW = (TWO - 1) * S + KS, PH = (THO - 1) * S + KS, NP = PW * PH;
   constexpr int LDS_FLOATS = (NP * LDSC > 4 * 32 * 33) ? NP * LDSC : 4 * 32 * 33;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
   const int b = mt / (tiles_x * tiles_y), rt = mt - b * tiles_x * tiles_y;
   const int oy0 = (rt / tiles_x) * THO, ox0 = (rt % tiles_x) * TWO;
   const int nf = blockIdx.y;
-  const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+  const int iy0 = oy0 * S - a.pad_y, ix0 = ox0 * S - a.pad_x;
   const int ncb = (a.Cin + CB - 1) / CB;
   const int li = lane & 31, lh = lane >> 5;
   const int a_base = (((li >> 3) * S) * PW + (li & 7) * S) * LDSC + 4 * lh;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
     const int nchunks = KK * nks;
     if (cb) __syncthreads();
     // ---- stage the input patch for this channel block (zero padding stays zero: transform only in-image pixels)
-    for (int q = tid; q < NP * 16; q += CONV_NT) {
+    for (int q = tid; q < ((a.dbg & 1) ? 0 : NP * 16); q += CONV_NT) {
       const int p = q >> 4, c4 = (q & 15) * 4;
       const int py = p / PW, px = p - py * PW;
       const int iy = iy0 + py, ix = ix0 + px, c = c0 + c4;
@@ -110,54 +115,73 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
     }
     __syncthreads();
 
-    // ---- this wave's share of the K chunks (chunk = one tap x 8 input channels = 4 MFMAs)
+    // ---- this wave's share of the K chunks (chunk = one tap x 8 input channels = 4 MFMAs).
+    // The loop body is ONE basic block of 6 chunks with two register sets (ping-pong, prefetch distance 3
+    // chunks) and no register moves, so hipcc keeps counted vmcnt waits.  A wave's chunk count is rounded
+    // up to a multiple of 6; surplus chunks read their B fragment from the zero pad behind the packed
+    // weights (pointer select, no branch) and so add nothing.
     const int cbeg = (nchunks * wave) >> 2, cend = (nchunks * (wave + 1)) >> 2;
+    const int nmine = cend - cbeg;
     const float* wblk = a.wp + ((size_t)(nf * ncb + cb) * KK * 8) * 256 + lane * 4;
-    auto bptr = [&](int c) {
-      c = c < cend ? c : cend - 1;  // clamp: never read past this wave's range
-      const int tap = c / nks, ks = c - tap * nks;
-      return reinterpret_cast<const f32x4*>(wblk + (size_t)(tap * 8 + ks) * 256);
+    const float* wzero = a.wp + (packed_floats(a.Cout, a.Cin, KK) - PACK_PAD) + lane * 4;
+    // cursors (wave-uniform scalars): A = chunk being multiplied, P = chunk being prefetched
+    int a_ks, a_dx, a_off, a_i = 0;
+    int p_ks, p_off, p_i = 0;
+    {
+      const int tap = cbeg / nks;
+      a_ks = cbeg - tap * nks;
+      const int dy = tap / a.ksx;
+      a_dx = tap - dy * a.ksx;
+      a_off = (dy * PW + a_dx) * LDSC + a_ks * 8;
+      p_ks = a_ks;
+      p_off = (tap * 8 + a_ks) * 256;
+    }
+    auto pf_load = [&]() {
+      const float* src = p_i < nmine ? wblk + p_off : wzero;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      const bool wrap = (p_ks + 1 == nks);
+      p_ks = wrap ? 0 : p_ks + 1;
+      p_off += wrap ? (9 - nks) * 256 : 256;
+      ++p_i;
+      return v;
     };
-    auto aread = [&](int c) {
-      const int tap = c / nks, ks = c - tap * nks;
-      const int dy = tap / KS, dx = tap - dy * KS;
-      return *reinterpret_cast<const f32x4*>(&lds[a_base + (dy * PW + dx) * LDSC + ks * 8]);
+    auto a_load = [&]() {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[a_base + a_off]);
+      const bool live = a_i + 1 < nmine;               // never walk the LDS cursor past the last real chunk
+      const bool wrap = (a_ks + 1 == nks);
+      const bool wrapx = wrap && (a_dx + 1 == a.ksx);
+      const int step = wrap ? (LDSC - 8 * (nks - 1)) + (wrapx ? (PW - a.ksx) * LDSC : 0) : 8;
+      a_off += live ? step : 0;
+      a_ks = wrap ? 0 : a_ks + 1;
+      a_dx = wrapx ? 0 : (wrap ? a_dx + 1 : a_dx);
+      ++a_i;
+      return v;
     };
-    if (cbeg < cend) {
-      f32x4 b0 = *bptr(cbeg), b1 = *bptr(cbeg + 1), b2 = *bptr(cbeg + 2), b3 = *bptr(cbeg + 3);
-      for (int c = cbeg; c < cend; c += 4) {
-        {
-          const f32x4 av = aread(c);
-          const f32x4 bn = *bptr(c + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b0[j], acc, 0, 0, 0);
-          b0 = bn;
-        }
-        if (c + 1 < cend) {
-          const f32x4 av = aread(c + 1);
-          const f32x4 bn = *bptr(c + 5);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b1[j], acc, 0, 0, 0);
-          b1 = bn;
-        }
-        if (c + 2 < cend) {
-          const f32x4 av = aread(c + 2);
-          const f32x4 bn = *bptr(c + 6);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b2[j], acc, 0, 0, 0);
-          b2 = bn;
-        }
-        if (c + 3 < cend) {
-          const f32x4 av = aread(c + 3);
-          const f32x4 bn = *bptr(c + 7);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b3[j], acc, 0, 0, 0);
-          b3 = bn;
-        }
+#define SST_CHUNK(BUSE, BLOAD)                                                                         \
+    {                                                                                                  \
+      const f32x4 av = a_load();                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], BUSE[j], acc, 0, 0, 0);                    \
+      BLOAD = pf_load();                                                                               \
+    }
+    if (nmine > 0 && !(a.dbg & 2)) {
+      f32x4 A0 = pf_load(), A1 = pf_load(), A2 = pf_load(), B0, B1, B2;
+      for (int c = 0; c < nmine; c += 6) {
+        SST_CHUNK(A0, B0)
+        SST_CHUNK(A1, B1)
+        SST_CHUNK(A2, B2)
+        SST_CHUNK(B0, A0)
+        SST_CHUNK(B1, A1)
+        SST_CHUNK(B2, A2)
       }
     }
+#undef SST_CHUNK
   }
 
+  if (a.dbg & 4) {
+    if (acc[0] == 12345.f) a.y[0] = acc[0];
+    return;
+  }
   // ---- reduce the 4 K-partials through LDS (overlays the patch)
   __syncthreads();
 #pragma unroll
@@ -210,12 +234,22 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
           if (a.y_pre) a.y_pre[o] = v[j];
           a.y[o] = fminf(fmaxf(v[j], 0.f), 1.f);
         }
-    } else {  // OUT_UNSHUFFLE
+    } else if (a.out_mode == OUT_UNSHUFFLE) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (n0 + j < a.Cout)
           a.y[(((size_t)b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * (4 * a.Cout) + 4 * (n0 + j) +
               2 * (oy & 1) + (ox & 1)] = v[j];
+    } else {  // OUT_STRIDE2: (Ho,Wo) is this parity class's sub-grid of the [Hy,Wy] tensor
+      const int Y = 2 * oy + a.sub_y, X = 2 * ox + a.sub_x;
+      float* d = a.y + (((size_t)b * a.Hy + Y) * a.Wy + X) * a.Cout + n0;
+      if ((a.Cout & 3) == 0 && n0 + 3 < a.Cout) {
+        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n0 + j < a.Cout) d[j] = v[j];
+      }
     }
   }
   if (a.stats) {
@@ -264,7 +298,8 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
 }
 
 // w [Cout][Cin][3][3] (reference layout) -> packed.  mode 0: forward.  mode 1: data-gradient of a stride-1
-// conv (outputs = Cin, inputs = Cout, taps rotated 180 degrees).
+// conv (outputs = Cin, inputs = Cout, taps rotated 180 degrees).  Stride-2 data-gradients use
+// pack_s2_dgrad_kernel below (one compact tap list per output-pixel parity class).
 __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KK,
                                  int mode, int64_t total) {
   const int O = mode ? Cin : Cout, I = mode ? Cout : Cin;
@@ -282,13 +317,46 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
     const int o = of * 32 + (l & 31);
     const int i = cbk * 64 + ks * 8 + (l >> 5) * 4 + j;
     float v = 0.f;
-    if (o < O && i < I) {
+    if (of < (O + 31) / 32 && o < O && i < I) {
       if (mode == 0)
         v = w[((size_t)o * Cin + i) * KK + tap];
       else
         v = w[((size_t)i * Cin + o) * KK + (KK - 1 - tap)];
     }
     wp[idx] = v;
+  }
+}
+
+// Data-gradient of a 3x3 / stride-2 / pad-1 conv, parity class (py,px) of the input-gradient pixel (iy,ix) =
+// (2a+py, 2b+px):  dX[iy,ix,ci] = sum over taps (jy,jx) of the class, co:  dY[a+jy, b+jx, co] * W[co][ci][ky][kx]
+// with ky = py ? (jy ? 0 : 2) : 1 (same for kx).  Class c = 2*py+px has (1+py)*(1+px) taps; the 4 classes are
+// packed back to back (offsets: s2_class_offset).
+__host__ __device__ inline int64_t s2_class_offset(int cls, int Cin, int Cout) {
+  int64_t off = 0;
+  for (int c = 0; c < cls; ++c) off += packed_floats(Cin, Cout, (1 + (c >> 1)) * (1 + (c & 1)));
+  return off;
+}
+__global__ void pack_s2_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+  const int cls = blockIdx.y, py = cls >> 1, px = cls & 1;
+  const int nty = 1 + py, ntx = 1 + px, KKc = nty * ntx;
+  const int O = Cin, I = Cout, ncb = (I + 63) / 64;
+  float* dst = wp + s2_class_offset(cls, Cin, Cout);
+  const int64_t total = packed_floats(O, I, KKc);
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx & 3, l = (idx >> 2) & 63, ks = (idx >> 8) & 7;
+    int64_t rest = idx >> 11;
+    const int tap = rest % KKc;
+    rest /= KKc;
+    const int cbk = rest % ncb;
+    const int of = rest / ncb;
+    const int o = of * 32 + (l & 31), i = cbk * 64 + ks * 8 + (l >> 5) * 4 + j;
+    float v = 0.f;
+    if (of < (O + 31) / 32 && o < O && i < I) {
+      const int jy = tap / ntx, jx = tap - jy * ntx;
+      const int ky = py ? (jy ? 0 : 2) : 1, kx = px ? (jx ? 0 : 2) : 1;
+      v = w[(((size_t)i * Cin + o) * 3 + ky) * 3 + kx];
+    }
+    dst[idx] = v;
   }
 }
 
@@ -321,14 +389,17 @@ SST_API int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre
   SST_REQUIRE(!(ksize == 9 && stride == 2), "sst_conv_fwd: 9x9 stride 2 not built");
   SST_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sst_conv_fwd: in_scale/in_shift must come together");
   SST_REQUIRE(!stats || stats_cnt, "sst_conv_fwd: stats needs stats_cnt");
+  const int dbg_bits = out_mode >> 8;   // undocumented ablation bits (tools/), 0 in production
+  out_mode &= 0xff;
   SST_REQUIRE(out_mode >= 0 && out_mode <= 3, "sst_conv_fwd: bad out_mode");
   SST_REQUIRE(out_mode != OUT_SHUFFLE || (Cout & 3) == 0, "sst_conv_fwd: shuffle store needs Cout %% 4 == 0");
   SST_REQUIRE(out_mode == OUT_NHWC || (!residual && !stats), "sst_conv_fwd: residual/stats only with NHWC store");
   Conv3Args a;
   a.x = x; a.wp = wp; a.y = y; a.y_pre = y_pre; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift;
   a.in_slope = in_slope; a.in_slope_const = in_slope_const; a.in_act = in_act; a.residual = residual; a.stats = stats;
-  a.stats_cnt = stats_cnt; a.out_mode = out_mode;
+  a.stats_cnt = stats_cnt; a.out_mode = out_mode; a.dbg = dbg_bits;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.ksy = a.ksx = ksize; a.pad_y = a.pad_x = ksize / 2; a.sub_y = a.sub_x = 0; a.Hy = a.Wy = 0;
   a.Ho = (H + 2 * (ksize / 2) - ksize) / stride + 1;
   a.Wo = (W + 2 * (ksize / 2) - ksize) / stride + 1;
   SST_REQUIRE(out_mode != OUT_UNSHUFFLE || ((a.Ho & 1) == 0 && (a.Wo & 1) == 0), "sst_conv_fwd: unshuffle needs even Ho,Wo");
@@ -343,5 +414,38 @@ SST_API int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre
   else
     conv_fwd_kernel<9, 1><<<grid, CONV_NT, 0, st>>>(a);
   SST_LAUNCH_CHECK("conv_fwd_kernel");
+  return SST_OK;
+}
+
+// ---- data-gradient of a 3x3 stride-2 pad-1 convolution (Discriminator.features, model.py:35,42,49,56)
+SST_API int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin) { return s2_class_offset(4, Cin, Cout); }
+
+SST_API int sst_conv_s2_dgrad_pack(const float* w, float* wp, int Cout, int Cin, void* stream) {
+  SST_REQUIRE(w && wp && Cout > 0 && Cin > 0, "sst_conv_s2_dgrad_pack: bad argument");
+  pack_s2_dgrad_kernel<<<dim3(256, 4), 256, 0, sst_stream(stream)>>>(w, wp, Cout, Cin);
+  SST_LAUNCH_CHECK("pack_s2_dgrad_kernel");
+  return SST_OK;
+}
+
+// dx [B,H,W,Cin] = conv_transpose(dy [B,Ho,Wo,Cout]) for y = conv3x3(x, stride 2, pad 1); 4 launches (parity classes).
+SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout,
+                              void* stream) {
+  SST_REQUIRE(dy && wp && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "sst_conv_s2_dgrad: bad argument");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    const int nh = (H - py + 1) / 2, nw = (W - px + 1) / 2;   // pixels of this parity class
+    if (nh <= 0 || nw <= 0) continue;
+    Conv3Args a;
+    a.x = dy; a.wp = wp + s2_class_offset(cls, Cin, Cout); a.y = dx; a.y_pre = nullptr; a.bias = nullptr;
+    a.in_scale = a.in_shift = a.in_slope = nullptr; a.in_slope_const = 0.f; a.in_act = ACT_NONE;
+    a.residual = nullptr; a.stats = nullptr; a.stats_cnt = nullptr; a.out_mode = OUT_STRIDE2; a.dbg = 0;
+    a.B = B; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin;     // roles swap: the "input" of this conv is dy
+    a.ksy = 1 + py; a.ksx = 1 + px; a.pad_y = a.pad_x = 0; a.sub_y = py; a.sub_x = px;
+    a.Ho = nh; a.Wo = nw; a.Hy = H; a.Wy = W;
+    dim3 grid((unsigned)sst_conv_mtiles(B, nh, nw), (Cin + 31) / 32);
+    conv_fwd_kernel<3, 1><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+    SST_LAUNCH_CHECK("conv_fwd_kernel<3,1> (s2 dgrad)");
+  }
   return SST_OK;
 }

@@ -1,0 +1,322 @@
+// Fully-connected layers of the discriminator classifier (reference model.py:61-65, 69-70):
+//   flatten(NCHW order) -> Linear(8C*(HR/16)^2 -> 1024) -> LeakyReLU(0.2) -> Linear(1024 -> 1)
+//
+// Linear-1 is HBM-bound (75.5 MB of fp32 weights for 0.6 GFLOP at B=16): every kernel here streams the
+// weight matrix exactly once in its reference layout [N][K] with 16-B lanes; the arithmetic rides along on
+// v_mfma_f32_16x16x4_f32 (M = batch <= 16 per tile) or plain FMAs.
+//   fwd   : y[m][n]  = sum_k x[m][k] w[n][k] (+ bias)          split-K over workgroups, slab reduce
+//   dgrad : dx[m][k] = sum_n dy[m][n] w[n][k]                   optional NHWC scatter of the k index
+//   wgrad : dw[n][k] = sum_m dy[m][n] x[m][k]                   rank-M update, write-bound
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int NT = 256;
+constexpr int MAXM = 64;   // batch rows supported (4 MFMA row tiles)
+
+// ---- forward: grid (N/16, ksplit); each wave walks its k range 16 at a time (one float4 per lane per operand)
+__global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ slab, int M, int N, int K, int kslice) {
+  __shared__ float red[4][MAXM][17];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lj = lane & 15, lq = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kb = blockIdx.y * kslice, ke = min(K, kb + kslice);
+  const int mt = (M + 15) / 16;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n = min(n0 + lj, N - 1);
+  const float* wrow = w + (size_t)n * K;
+  for (int k = kb + wave * 16; k < ke; k += 64) {
+    const int kk = k + 4 * lq;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (kk + 3 < ke) {
+      bv = *reinterpret_cast<const f32x4*>(wrow + kk);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (kk + j < ke) bv[j] = wrow[kk + j];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < mt) {
+        const int m = t * 16 + lj;
+        f32x4 av = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+          if (kk + 3 < ke) {
+            av = *reinterpret_cast<const f32x4*>(x + (size_t)m * K + kk);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (kk + j < ke) av[j] = x[(size_t)m * K + kk + j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // acc[t][r]: row m = 16t + 4*lq + r, col n = n0 + lj
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][t * 16 + 4 * lq + r][lj] = acc[t][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < M * 16; i += NT) {
+    const int m = i >> 4, j = i & 15;
+    if (n0 + j < N)
+      slab[((size_t)blockIdx.y * M + m) * N + n0 + j] = red[0][m][j] + red[1][m][j] + red[2][m][j] + red[3][m][j];
+  }
+}
+
+// y[m][n] = bias[n] + sum_s slab[s][m][n]
+__global__ __launch_bounds__(NT) void linear_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int nslab, int M, int N) {
+  const int total = M * N;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
+    float t = bias ? bias[i % N] : 0.f;
+    for (int s = 0; s < nslab; ++s) t += slab[(size_t)s * total + i];
+    y[i] = t;
+  }
+}
+
+// ---- dgrad: grid (K/64); wave w handles n in [w*N/4, (w+1)*N/4), 4 rows of W per step, 64 k-columns per workgroup.
+// Lane (lj, lq) loads float4 W[n+lq][k0 + 4 lj ..]: MFMA t (t = 0..3) uses element t => column k0 + 4 lj + t.
+__global__ __launch_bounds__(NT) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int M, int N, int K, int C, int HW) {
+  __shared__ float red[4][16][65];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lj = lane & 15, lq = lane >> 4;
+  const int k0 = blockIdx.x * 64;
+  const int nper = ((N + 3) / 4 + 3) / 4 * 4;
+  const int nb = wave * nper, ne = min(N, nb + nper);
+  const int mt = (M + 15) / 16;
+  for (int t0 = 0; t0 < mt; ++t0) {          // one 16-row batch tile at a time (M <= 16 in the hot path)
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m = t0 * 16 + lj;
+    for (int n = nb; n < ne; n += 4) {
+      const int nn = n + lq;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      float av = 0.f;
+      if (nn < ne) {
+        const int kk = k0 + 4 * lj;
+        if (kk + 3 < K) {
+          bv = *reinterpret_cast<const f32x4*>(w + (size_t)nn * K + kk);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kk + j < K) bv[j] = w[(size_t)nn * K + kk + j];
+        }
+        if (m < M) av = dy[(size_t)m * N + nn];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][4 * lq + r][4 * lj + t] = acc[t][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 64; i += NT) {
+      const int mm = i >> 6, kc = i & 63, mg = t0 * 16 + mm, k = k0 + kc;
+      if (mg < M && k < K) {
+        const float v = red[0][mm][kc] + red[1][mm][kc] + red[2][mm][kc] + red[3][mm][kc];
+        // k indexes the NCHW flatten (c, hw); HW > 0 scatters to NHWC [M][HW][C]
+        const size_t o = HW > 0 ? (size_t)mg * K + (size_t)(k % HW) * C + k / HW : (size_t)mg * K + k;
+        dx[o] = v;
+      }
+    }
+  }
+}
+
+// ---- wgrad: grid (K/1024, N/16); thread owns 4 consecutive k; dw[n][k] (+)= sum_m dy[m][n] x[m][k]
+__global__ __launch_bounds__(NT) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ dw, int M, int N, int K, int accumulate) {
+  __shared__ float sdy[MAXM][16];
+  const int n0 = blockIdx.y * 16;
+  for (int i = threadIdx.x; i < M * 16; i += NT) {
+    const int m = i >> 4, j = i & 15;
+    sdy[m][j] = (n0 + j < N) ? dy[(size_t)m * N + n0 + j] : 0.f;
+  }
+  __syncthreads();
+  const int k = (blockIdx.x * NT + threadIdx.x) * 4;
+  if (k >= K) return;
+  const bool vec = (K & 3) == 0;
+  f32x4 acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < M; ++m) {
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * K + k);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k + j < K) xv[j] = x[(size_t)m * K + k + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] += sdy[m][j] * xv;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (n0 + j >= N) break;
+    float* d = dw + (size_t)(n0 + j) * K + k;
+    if (vec) {
+      f32x4 o = acc[j];
+      if (accumulate) o += *reinterpret_cast<f32x4*>(d);
+      *reinterpret_cast<f32x4*>(d) = o;
+    } else {
+      for (int q = 0; q < 4; ++q)
+        if (k + q < K) d[q] = accumulate ? d[q] + acc[j][q] : acc[j][q];
+    }
+  }
+}
+
+// db[n] (+)= sum_m dy[m][n]
+__global__ void colsum_small_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) {
+    float t = 0.f;
+    for (int m = 0; m < M; ++m) t += dy[(size_t)m * N + n];
+    db[n] = accumulate ? db[n] + t : t;
+  }
+}
+
+// ---- the tiny head: y[m][n] = b[n] + sum_k lrelu(h[m][k]) w[n][k]   (N small); one workgroup per (m,n)
+__global__ __launch_bounds__(NT) void head_fwd_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ y, int M, int N, int K,
+                                                      float slope) {
+  __shared__ float red[NT / 64];
+  const int m = blockIdx.x / N, n = blockIdx.x - m * N;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += NT) {
+    float v = h[(size_t)m * K + k];
+    v = v > 0.f ? v : v * slope;
+    s = fmaf(v, w[(size_t)n * K + k], s);
+  }
+  s = block_sum<NT>(s, red);
+  if (threadIdx.x == 0) y[(size_t)m * N + n] = s + (b ? b[n] : 0.f);
+}
+
+// backward of the head: dh[m][k] = lrelu'(h) * sum_n dy[m][n] w[n][k];  dw[n][k] (+)= sum_m dy[m][n] lrelu(h[m][k]);
+// db[n] (+)= sum_m dy[m][n].   grid over k.
+__global__ __launch_bounds__(NT) void head_bwd_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                      const float* __restrict__ dy, float* __restrict__ dh,
+                                                      float* __restrict__ dw, float* __restrict__ db, int M, int N, int K,
+                                                      float slope, int accumulate) {
+  const int k = blockIdx.x * NT + threadIdx.x;
+  if (k < K) {
+    for (int n = 0; n < N; ++n) {
+      float t = 0.f;
+      for (int m = 0; m < M; ++m) {
+        float v = h[(size_t)m * K + k];
+        v = v > 0.f ? v : v * slope;
+        t = fmaf(dy[(size_t)m * N + n], v, t);
+      }
+      if (dw) dw[(size_t)n * K + k] = accumulate ? dw[(size_t)n * K + k] + t : t;
+    }
+    for (int m = 0; m < M; ++m) {
+      float t = 0.f;
+      for (int n = 0; n < N; ++n) t = fmaf(dy[(size_t)m * N + n], w[(size_t)n * K + k], t);
+      dh[(size_t)m * K + k] = h[(size_t)m * K + k] > 0.f ? t : t * slope;
+    }
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x < N) {
+    float t = 0.f;
+    for (int m = 0; m < M; ++m) t += dy[(size_t)m * N + threadIdx.x];
+    db[threadIdx.x] = accumulate ? db[threadIdx.x] + t : t;
+  }
+}
+
+// flat[b][c*HW + hw] = act(y[b][hw][c] * scale[c] + shift[c])        (NHWC -> NCHW flatten, model.py:69)
+__global__ __launch_bounds__(NT) void flatten_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float slope, int act,
+                                                         float* __restrict__ flat, int B, int HW, int C) {
+  const int64_t total = (int64_t)B * HW * C;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int hw = (int)(p % HW);
+    const int64_t b = p / HW;
+    float v = y[i];
+    if (scale) v = fmaf(v, scale[c], shift[c]);
+    if (act) v = v > 0.f ? v : v * slope;
+    flat[(b * C + c) * HW + hw] = v;
+  }
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+SST_API int sst_linear_ksplit(int M, int N, int K) {
+  int ks = 1024 / ((N + 15) / 16);          // ~1024 workgroups
+  if (ks < 1) ks = 1;
+  while (ks > 1 && K / ks < 256) ks >>= 1;  // at least 256 k per slice
+  return ks;
+}
+
+SST_API int sst_linear_fwd(const float* x, const float* w, const float* bias, float* y, float* slab, int M, int N, int K,
+                           void* stream) {
+  SST_REQUIRE(x && w && y && slab && M > 0 && M <= MAXM && N > 0 && K > 0, "sst_linear_fwd: bad argument (M=%d)", M);
+  const int ks = sst_linear_ksplit(M, N, K);
+  const int kslice = ((K + ks - 1) / ks + 63) / 64 * 64;
+  dim3 grid((N + 15) / 16, (K + kslice - 1) / kslice);
+  linear_fwd_kernel<<<grid, NT, 0, sst_stream(stream)>>>(x, w, slab, M, N, K, kslice);
+  SST_LAUNCH_CHECK("linear_fwd_kernel");
+  const int rb = (M * N + NT - 1) / NT;
+  linear_reduce_kernel<<<rb < 512 ? rb : 512, NT, 0, sst_stream(stream)>>>(slab, bias, y, grid.y, M, N);
+  SST_LAUNCH_CHECK("linear_reduce_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_linear_dgrad(const float* dy, const float* w, float* dx, int M, int N, int K, int nhwc_C, int nhwc_HW,
+                             void* stream) {
+  SST_REQUIRE(dy && w && dx && M > 0 && M <= MAXM && N > 0 && K > 0, "sst_linear_dgrad: bad argument");
+  SST_REQUIRE(nhwc_HW == 0 || nhwc_C * nhwc_HW == K, "sst_linear_dgrad: C*HW must equal K");
+  linear_dgrad_kernel<<<(K + 63) / 64, NT, 0, sst_stream(stream)>>>(dy, w, dx, M, N, K, nhwc_C, nhwc_HW);
+  SST_LAUNCH_CHECK("linear_dgrad_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, int accumulate,
+                             void* stream) {
+  SST_REQUIRE(dy && x && dw && M > 0 && M <= MAXM && N > 0 && K > 0, "sst_linear_wgrad: bad argument");
+  dim3 grid((K + 4 * NT - 1) / (4 * NT), (N + 15) / 16);
+  linear_wgrad_kernel<<<grid, NT, 0, sst_stream(stream)>>>(dy, x, dw, M, N, K, accumulate);
+  SST_LAUNCH_CHECK("linear_wgrad_kernel");
+  if (db) {
+    colsum_small_kernel<<<(N + 255) / 256, 256, 0, sst_stream(stream)>>>(dy, db, M, N, accumulate);
+    SST_LAUNCH_CHECK("colsum_small_kernel");
+  }
+  return SST_OK;
+}
+
+SST_API int sst_head_fwd(const float* h, const float* w, const float* b, float* y, int M, int N, int K, float slope,
+                         void* stream) {
+  SST_REQUIRE(h && w && y && M > 0 && N > 0 && N <= 64 && K > 0, "sst_head_fwd: bad argument");
+  head_fwd_kernel<<<M * N, NT, 0, sst_stream(stream)>>>(h, w, b, y, M, N, K, slope);
+  SST_LAUNCH_CHECK("head_fwd_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_head_bwd(const float* h, const float* w, const float* dy, float* dh, float* dw, float* db, int M, int N,
+                         int K, float slope, int accumulate, void* stream) {
+  SST_REQUIRE(h && w && dy && dh && M > 0 && N > 0 && N <= 64 && K > 0, "sst_head_bwd: bad argument");
+  head_bwd_kernel<<<(K + NT - 1) / NT, NT, 0, sst_stream(stream)>>>(h, w, dy, dh, dw, db, M, N, K, slope, accumulate);
+  SST_LAUNCH_CHECK("head_bwd_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_flatten_act(const float* y, const float* scale, const float* shift, float slope, int act, float* flat,
+                            int B, int HW, int C, void* stream) {
+  SST_REQUIRE(y && flat && B > 0 && HW > 0 && C > 0 && ((scale == nullptr) == (shift == nullptr)), "sst_flatten_act: bad argument");
+  const int64_t total = (int64_t)B * HW * C;
+  const int blocks = (int)((total + NT - 1) / NT < 2048 ? (total + NT - 1) / NT : 2048);
+  flatten_act_kernel<<<blocks, NT, 0, sst_stream(stream)>>>(y, scale, shift, slope, act, flat, B, HW, C);
+  SST_LAUNCH_CHECK("flatten_act_kernel");
+  return SST_OK;
+}

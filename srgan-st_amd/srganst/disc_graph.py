@@ -1,0 +1,121 @@
+"""Kernel graph of the VGG-style discriminator: forward and hand-written backward over srganst.ops.
+
+Forward = reference model.py:67-71 over the layer list model.py:30-65; backward = what autograd
+derives.  NHWC activations; conv outputs are kept pre-BatchNorm / pre-activation and the
+BN-apply + LeakyReLU(0.2) is fused into the consumer's load.  The flatten (model.py:69) keeps the
+reference's (C,H,W) order so classifier.0.weight is used in its reference layout.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import ACT_SLOPE
+
+LRELU = 0.2
+# (conv index, bn index or None, stride) in module.features                           model.py:30-59
+PLAN = [(0, None, 1), (2, 3, 2), (5, 6, 1), (8, 9, 2), (11, 12, 1), (14, 15, 2), (17, 18, 1), (20, 21, 2)]
+
+
+def forward(module, x, p, training):
+    sv = {"layers": []}
+    x3 = ops.transpose(x.contiguous(), to_nchw=False)
+    h, scale, shift, act = x3, None, None, 0
+    for ci, bi, stride in PLAN:
+        w = p[f"features.{ci}.weight"]
+        cout = w.shape[0]
+        bias = p.get(f"features.{ci}.bias")
+        y, _, st, cnt = ops.conv_fwd(h, ops.pack_conv(w), cout, 3, stride, bias=bias, in_scale=scale, in_shift=shift,
+                                     in_slope_const=LRELU, in_act=act, want_stats=(bi is not None and training))
+        rec = {"x": h, "x_scale": scale, "x_shift": shift, "x_act": act, "y": y, "ci": ci, "bi": bi, "stride": stride}
+        if bi is not None:
+            bn = module.features[bi]
+            g, b = p[f"features.{bi}.weight"], p[f"features.{bi}.bias"]
+            if training:
+                mean, rstd, scale, shift = ops.bn_finalize(st, cnt, g, b, bn.running_mean, bn.running_var)
+                bn.num_batches_tracked.add_(1)
+                rec["mean"], rec["rstd"] = mean, rstd
+            else:
+                scale, shift = ops.bn_eval_affine(g, b, bn.running_mean, bn.running_var)
+        else:
+            scale = shift = None
+        rec["scale"], rec["shift"] = scale, shift
+        sv["layers"].append(rec)
+        h, act = y, ACT_SLOPE
+    flat = ops.flatten_act(h, scale, shift, LRELU, 1)                       # [B, C*H*W]  (C,H,W) order
+    h1 = ops.linear_fwd(flat, p["classifier.0.weight"], p["classifier.0.bias"])   # pre-activation
+    out = ops.head_fwd(h1, p["classifier.2.weight"], p["classifier.2.bias"], LRELU)
+    sv["flat"], sv["h1"] = flat, h1
+    return out, sv
+
+
+def backward(module, p, sv, dout, need_param_grads, need_dx):
+    grads = {}
+
+    def G(name):
+        t = torch.empty_like(p[name])
+        grads[name] = t
+        return t
+
+    h1, flat = sv["h1"], sv["flat"]
+    wg = need_param_grads
+    dh1 = ops.head_bwd(h1, p["classifier.2.weight"], dout.contiguous(), LRELU,
+                       dw=G("classifier.2.weight") if wg else None, db=G("classifier.2.bias") if wg else None)
+    if wg:
+        ops.linear_wgrad(dh1, flat, G("classifier.0.weight"), G("classifier.0.bias"))
+    last = sv["layers"][-1]
+    B, H, W, C = last["y"].shape
+    g = ops.linear_dgrad(dh1, p["classifier.0.weight"], nhwc=(C, H * W)).view(B, H, W, C)   # d LReLU(BN(y_last)) in NHWC
+    dx = None
+    for li in reversed(range(len(sv["layers"]))):
+        r = sv["layers"][li]
+        y = r["y"]
+        n = y.numel() // y.shape[-1]
+        ci, bi = r["ci"], r["bi"]
+        w = p[f"features.{ci}.weight"]
+        part = ops.bwd_reduce(g, y, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1)
+        if bi is not None:
+            gam = p[f"features.{bi}.weight"]
+            dg = G(f"features.{bi}.weight") if wg else torch.empty_like(gam)
+            db = G(f"features.{bi}.bias") if wg else torch.empty_like(gam)
+            cA, cB, cC = ops.bwd_finalize(part, n, r["mean"], r["rstd"], gam, dg, db)
+            dy = ops.bwd_apply(g, y, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1, cA=cA, cB=cB, cC=cC)
+        else:
+            ops.bwd_finalize(part, n, dbeta=G(f"features.{ci}.bias") if wg else None)
+            dy = ops.bwd_apply(g, y, slope_const=LRELU, act=1)
+        if wg:
+            ops.conv_wgrad(r["x"], dy, G(f"features.{ci}.weight"), 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
+                           in_slope_const=LRELU, in_act=r["x_act"])
+        if li == 0 and not need_dx:
+            break
+        xin = r["x"]
+        if r["stride"] == 1:
+            g = ops.conv_fwd(dy, ops.pack_conv(w, 1), w.shape[1], 3, 1)[0]
+        else:
+            g = ops.conv_s2_dgrad(dy, ops.pack_conv_s2_dgrad(w), xin.shape[1], xin.shape[2], w.shape[1])
+        if li == 0:
+            dx = ops.transpose(g, to_nchw=True)
+    return grads, dx
+
+
+class DiscriminatorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, grad_mode, *params):
+        names = [n for n, _ in module.named_parameters()]
+        p = dict(zip(names, [t.detach() for t in params]))
+        need_param = grad_mode and any(ctx.needs_input_grad[3:])
+        need_dx = grad_mode and ctx.needs_input_grad[0]
+        need_grad = need_param or need_dx
+        if need_grad and not module.training:
+            raise NotImplementedError("Discriminator backward in eval() mode is not on the reference's path (train.py:110)")
+        out, sv = forward(module, x, p, module.training)
+        if need_grad:
+            ctx.module, ctx.sv, ctx.p, ctx.names = module, sv, p, names
+            ctx.need_param, ctx.need_dx = need_param, need_dx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads, dx = backward(ctx.module, ctx.p, ctx.sv, dout, ctx.need_param, ctx.need_dx)
+        ctx.sv = None
+        return (dx, None, None, *[grads.get(n) for n in ctx.names])

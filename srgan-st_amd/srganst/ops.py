@@ -221,3 +221,73 @@ def bce_logits(logits, target, want_loss=True, want_grad=False, scale_dev=None, 
     check(_abi.lib().sst_bce_logits(ptr(logits), float(target), ptr(loss), ptr(dl), ptr(scale_dev), float(scale_host),
                                     logits.numel(), stream_ptr()), "sst_bce_logits")
     return loss, dl
+
+
+def pack_conv_s2_dgrad(w):
+    cout, cin, k, _ = w.shape
+    assert k == 3
+    wp = _f32(_abi.lib().sst_conv_s2_dgrad_packed_floats(cout, cin), like=w)
+    check(_abi.lib().sst_conv_s2_dgrad_pack(ptr(w), ptr(wp), cout, cin, stream_ptr()), "sst_conv_s2_dgrad_pack")
+    return wp
+
+
+def conv_s2_dgrad(dy, wp, H, W, cin):
+    """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] for y = conv3x3(x, stride 2, pad 1)."""
+    B, ho, wo, cout = dy.shape
+    dx = _f32(B, H, W, cin, like=dy)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv_s2_dgrad(ptr(dy), ptr(wp), ptr(dx), B, H, W, cin, cout, stream_ptr()), "sst_conv_s2_dgrad")
+    _prof_end(e0, "conv_fwd_kernel<3,1>(s2-dgrad x4)", 2.0 * B * ho * wo * cout * cin * 9)
+    return dx
+
+
+def linear_fwd(x, w, bias):
+    M, K = x.shape
+    N = w.shape[0]
+    y = _f32(M, N, like=x)
+    slab = _f32(_abi.lib().sst_linear_ksplit(M, N, K) * M * N, like=x)
+    check(_abi.lib().sst_linear_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), ptr(slab), M, N, K, stream_ptr()), "sst_linear_fwd")
+    return y
+
+
+def linear_dgrad(dy, w, nhwc=None):
+    """dx [M,K]; nhwc=(C,HW): K indexes an NCHW flatten and dx is written as NHWC [M,HW,C]."""
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = _f32(M, K, like=dy)
+    c, hw = nhwc if nhwc else (0, 0)
+    check(_abi.lib().sst_linear_dgrad(ptr(dy), ptr(w), ptr(dx), M, N, K, c, hw, stream_ptr()), "sst_linear_dgrad")
+    return dx
+
+
+def linear_wgrad(dy, x, dw, db=None, accumulate=False):
+    M, N = dy.shape
+    K = x.shape[1]
+    check(_abi.lib().sst_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), M, N, K, int(accumulate), stream_ptr()),
+          "sst_linear_wgrad")
+
+
+def head_fwd(h, w, b, slope):
+    M, K = h.shape
+    N = w.shape[0]
+    y = _f32(M, N, like=h)
+    check(_abi.lib().sst_head_fwd(ptr(h), ptr(w), ptr(b), ptr(y), M, N, K, float(slope), stream_ptr()), "sst_head_fwd")
+    return y
+
+
+def head_bwd(h, w, dy, slope, dw=None, db=None, accumulate=False):
+    M, K = h.shape
+    N = w.shape[0]
+    dh = torch.empty_like(h)
+    check(_abi.lib().sst_head_bwd(ptr(h), ptr(w), ptr(dy), ptr(dh), ptr(dw), ptr(db), M, N, K, float(slope), int(accumulate),
+                                  stream_ptr()), "sst_head_bwd")
+    return dh
+
+
+def flatten_act(y, scale, shift, slope, act=1):
+    """NHWC [B,H,W,C] -> [B, C*H*W] in NCHW-flatten order with act(y*scale+shift) applied."""
+    B, H, W, C = y.shape
+    flat = _f32(B, C * H * W, like=y)
+    check(_abi.lib().sst_flatten_act(ptr(y), ptr(scale), ptr(shift), float(slope), int(act), ptr(flat), B, H * W, C,
+                                     stream_ptr()), "sst_flatten_act")
+    return flat

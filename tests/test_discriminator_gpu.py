@@ -1,0 +1,213 @@
+"""GPU parity of the discriminator path + the full SRGAN iteration against the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from srganst import ops
+    return ops
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 13, 9, 8, 16), (2, 12, 12, 128, 128), (1, 6, 6, 64, 32), (1, 7, 10, 64, 64)])
+def test_conv_s2_dgrad(ops, case):
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    y = F.conv2d(x, w.double(), None, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    dx = ops.conv_s2_dgrad(nhwc(dy).cuda(), ops.pack_conv_s2_dgrad(w.cuda()), H, W, Cin)
+    assert rel_err(nchw(dx.cpu()), x.grad) < TOL
+
+
+@pytest.mark.parametrize("case", [(16, 1024, 18432), (4, 40, 576), (16, 1024, 1000), (33, 24, 100)])
+def test_linear_fwd_dgrad_wgrad(ops, case):
+    M, N, K = case
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(M, K, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(N, K, generator=g, dtype=torch.float64) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.linear(x, w, b)
+    dy = torch.randn(M, N, generator=g)
+    y.backward(dy.double())
+    xd, wd, bd, dyd = x.detach().float().cuda(), w.detach().float().cuda(), b.detach().float().cuda(), dy.cuda()
+    assert rel_err(ops.linear_fwd(xd, wd, bd).cpu(), y.detach()) < TOL
+    assert rel_err(ops.linear_dgrad(dyd, wd).cpu(), x.grad) < TOL
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    ops.linear_wgrad(dyd, xd, dw, db)
+    assert rel_err(dw.cpu(), w.grad) < TOL and rel_err(db.cpu(), b.grad) < TOL
+
+
+def test_linear_dgrad_nhwc_scatter_and_flatten(ops):
+    B, C, H, W, N = 3, 8, 3, 5, 24
+    g = torch.Generator().manual_seed(23)
+    y = torch.randn(B, C, H, W, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ref = F.leaky_relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2).flatten(1)
+    flat = ops.flatten_act(nhwc(y).cuda(), sc.cuda(), sh.cuda(), 0.2, 1)
+    assert torch.allclose(flat.cpu(), ref, rtol=1e-6, atol=1e-6)
+    w = torch.randn(N, C * H * W, generator=g)
+    dy = torch.randn(B, N, generator=g)
+    dflat = dy.double() @ w.double()
+    dx = ops.linear_dgrad(dy.cuda(), w.cuda(), nhwc=(C, H * W)).view(B, H, W, C)
+    assert rel_err(nchw(dx.cpu()).flatten(1), dflat) < TOL
+
+
+def test_head(ops):
+    g = torch.Generator().manual_seed(24)
+    h = torch.randn(16, 1024, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(1, 1024, generator=g, dtype=torch.float64) / 32).requires_grad_(True)
+    b = torch.randn(1, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.linear(F.leaky_relu(h, 0.2), w, b)
+    dy = torch.randn(16, 1, generator=g)
+    y.backward(dy.double())
+    hd, wd, bd = h.detach().float().cuda(), w.detach().float().cuda(), b.detach().float().cuda()
+    assert rel_err(ops.head_fwd(hd, wd, bd, 0.2).cpu(), y.detach()) < TOL
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    dh = ops.head_bwd(hd, wd, dy.cuda(), 0.2, dw, db)
+    assert rel_err(dh.cpu(), h.grad) < TOL and rel_err(dw.cpu(), w.grad) < TOL and rel_err(db.cpu(), b.grad) < TOL
+
+
+def test_bce_logits(ops):
+    x = torch.randn(16, 1, dtype=torch.float64, requires_grad=True)
+    for t in (0.9, 0.0):
+        x.grad = None
+        l = F.binary_cross_entropy_with_logits(x, torch.full_like(x, t))
+        (l * 0.5).backward()
+        loss, dl = ops.bce_logits(x.detach().float().cuda(), t, True, True, scale_host=0.5)
+        assert abs(loss.item() - l.item()) < 1e-6 and rel_err(dl.cpu(), x.grad) < 1e-5
+
+
+def make_cfg(ch=64, rcb=16, dch=64):
+    from srganst.config import Config
+    cfg = Config()
+    cfg.MODEL.G_N_CHANNEL, cfg.MODEL.G_N_RCB, cfg.MODEL.D_N_CHANNEL = ch, rcb, dch
+    return cfg
+
+
+def test_discriminator_full_seed0(golden):
+    from srganst.model import Discriminator
+    from srganst.loss import BCEWithLogitsLoss
+    g = golden("d_full_seed0")
+    torch.manual_seed(0)
+    D = Discriminator(make_cfg())
+    assert sum(p.numel() for p in D.parameters()) == 23563649            # reference model.py:194
+    assert torch.equal(D.state_dict()["features.0.weight"], T(g["w/features.0.weight"]))
+    D.cuda().train()
+    x = T(g["x"]).cuda().requires_grad_(True)
+    logit = D(x)
+    assert torch.allclose(logit.detach().cpu(), T(g["logit"]), rtol=1e-3, atol=1e-4)
+    loss = BCEWithLogitsLoss()(logit, torch.full([2, 1], 0.9).cuda())
+    assert abs(loss.item() - g["loss"].item()) < 1e-4
+    loss.backward()
+    assert rel_err(x.grad.cpu(), g["dx"]) < 5e-3
+    norms = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
+    for k, v in D.named_parameters():
+        assert abs(v.grad.norm().item() - norms[k]) <= 5e-3 * norms[k] + 1e-9, k
+    named = dict(D.named_parameters())
+    for f in g.files:
+        if f.startswith("g/") and "#" not in f:
+            assert rel_err(named[f[2:]].grad.cpu(), g[f]) < 5e-3, f
+        elif f.startswith("g/") and f.endswith("#head4"):
+            assert rel_err(named[f[2:-6]].grad[:4].cpu(), g[f]) < 5e-3, f
+
+
+def test_gan_iteration_small_golden(golden):
+    """One full train.py iteration through TrainEngine (eager): losses, all grads via Adam-updated states, D BN counters."""
+    from srganst.engine import TrainEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+    g = golden("gan_small_iter")
+    cfg = make_cfg(8, 2, 4)
+    torch.manual_seed(0)
+    D = Discriminator(cfg)                       # same construction order as the fixture: D then G
+    G = Generator(cfg)
+    for k, v in D.state_dict().items():
+        key = "d_state0/" + k
+        if key in g.files:
+            assert torch.equal(v, T(g[key])), k
+    D.cuda().train()
+    G.cuda().train()
+    cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+    cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+    cfg.SOLVER.D_UPDATE_INTERVAL = 1
+    eng = TrainEngine(cfg, G, D, use_graph=False)
+    losses, d_loss = eng.step(T(g["gt"]).cuda(), T(g["lr"]).cuda())
+    assert rel_err(eng.sr.cpu(), g["sr"]) < 1e-4
+    for name in ("Adversarial", "Pixel", "ST"):
+        assert abs(losses[name].item() - g["g_loss/" + name].item()) < 1e-3 * abs(g["g_loss/" + name].item()), name
+    assert abs(d_loss.item() - g["d_loss"].item()) < 1e-4
+    assert torch.allclose(eng.pred_gt.cpu(), T(g["pred_gt"]), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(eng.pred_sr.cpu(), T(g["pred_sr"]), rtol=1e-3, atol=1e-4)
+    for n, p in D.named_parameters():
+        key = "d_grad/" + n
+        if key in g.files:
+            assert rel_err(p.grad.cpu(), g[key]) < 5e-3, n
+        else:
+            assert abs(p.grad.double().norm().item() - g[key + "#norm"].item()) < 5e-3 * g[key + "#norm"].item(), n
+    sd = D.state_dict()
+    for k in sd:
+        key = "d_state1/" + k
+        if key not in g.files:
+            continue
+        if "num_batches" in k:
+            assert int(sd[k]) == int(g[key]) == 3          # D(sr) in the G step + D(gt) + D(sr) in the D step
+        else:
+            assert torch.allclose(sd[k].cpu(), T(g[key]), rtol=1e-3, atol=2e-4), k
+    sg = G.state_dict()
+    for k in sg:
+        if "num_batches" not in k:
+            assert torch.allclose(sg[k].cpu(), T(g["g_state1/" + k]), rtol=1e-3, atol=2e-4), k
+
+
+def test_train_engine_graph_equals_eager():
+    """hipGraph replay of the train step == eager step (same kernels, same order)."""
+    from srganst.engine import TrainEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+
+    def run(use_graph):
+        cfg = make_cfg(16, 2, 8)
+        torch.manual_seed(1)
+        D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
+        cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+        cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+        cfg.SOLVER.D_UPDATE_INTERVAL = 1
+        eng = TrainEngine(cfg, G, D, use_graph=use_graph)
+        gen = torch.Generator().manual_seed(2)
+        for _ in range(5):
+            gt = torch.rand(4, 3, 96, 96, generator=gen).cuda()
+            lr = torch.rand(4, 3, 24, 24, generator=gen).cuda()
+            eng.step(gt, lr)
+        torch.cuda.synchronize()
+        return G.state_dict(), D.state_dict(), {k: v.item() for k, v in eng.loss_values.items()}
+
+    g1, d1, l1 = run(False)
+    g2, d2, l2 = run(True)
+    for k in g1:
+        assert torch.allclose(g1[k].float(), g2[k].float(), rtol=1e-4, atol=1e-5), k
+    for k in d1:
+        assert torch.allclose(d1[k].float(), d2[k].float(), rtol=1e-4, atol=1e-5), k
+    for k in l1:
+        assert abs(l1[k] - l2[k]) <= 1e-4 * abs(l1[k]) + 1e-7
