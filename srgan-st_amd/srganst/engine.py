@@ -24,6 +24,9 @@ from . import dist as sdist
 def make_adam(params, lr, betas, eps, weight_decay, capturable):
     # torch.optim.Adam is third-party arithmetic the reference uses as-is (train.py:62-75); fused=True runs the
     # same update in a handful of multi-tensor launches and is graph-capturable.
+    params = list(params)
+    if capturable:      # lr as a device tensor: LR schedulers fill_() it in place, so a captured graph sees the new value
+        lr = torch.tensor(float(lr), device=params[0].device, dtype=torch.float32)
     return torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True,
                             capturable=capturable)
 

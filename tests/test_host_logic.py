@@ -1,0 +1,131 @@
+"""CPU: host-side mirror of the reference interface - config surface, parameter trees, init RNG order,
+checkpoint key handling, metrics, bicubic LR synthesis - against the golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_config_surface_matches_reference_defaults():
+    from srganst.config import Config
+    c = Config()
+    # reference config.py:19-119
+    assert c.EXP.N_EPOCHS == 40 and c.EXP.LABEL_SMOOTHING == 0.1 and c.LOG_TRAIN_PERIOD == 100
+    assert c.DATA.SEED == 0 and c.DATA.UPSCALE_FACTOR == 4 and c.DATA.BATCH_SIZE == 16 and c.DATA.GT_IMAGE_SIZE == 96
+    assert (c.MODEL.G_IN_CHANNEL, c.MODEL.G_OUT_CHANNEL, c.MODEL.G_N_CHANNEL, c.MODEL.G_N_RCB) == (3, 3, 64, 16)
+    assert (c.MODEL.D_IN_CHANNEL, c.MODEL.D_OUT_CHANNEL, c.MODEL.D_N_CHANNEL) == (3, 1, 64)
+    assert c.MODEL.G_LOSS.VGG19_LAYERS == {"features.17": 1 / 8, "features.26": 1 / 4, "features.35": 1 / 2}
+    assert list(c.MODEL.G_LOSS.CRITERIONS) == ["Adversarial"]
+    w = c.MODEL.G_LOSS.CRITERION_WEIGHTS
+    assert w["Adversarial"] == 0.001 and w["Pixel"] == 1.0 and w["ST"] == 1 / 3 and w["ContentVGG"] == 1.0
+    assert list(c.MODEL.G_LOSS.WARMUP_CRITERIONS) == ["Pixel"] and c.MODEL.G_LOSS.WARMUP_WEIGHTS["Pixel"] == 1.0
+    s = c.SOLVER
+    assert (s.D_UPDATE_INTERVAL, s.G_BASE_LR, s.G_BETA1, s.G_BETA2, s.G_EPS, s.G_WEIGHT_DECAY) == (100, 1e-4, 0.9, 0.999, 1e-4, 0)
+    assert (s.D_BASE_LR, s.D_BETA1, s.D_BETA2, s.D_EPS) == (1e-4, 0.9, 0.999, 1e-4)
+    assert c.SCHEDULER.STEP_SIZE == 20 and c.SCHEDULER.GAMMA == 0.5
+    c.add_g_criterion("ST", object(), 1 / 3)
+    assert "ST" in c.MODEL.G_LOSS.CRITERIONS
+    c.remove_g_criterion("ST")
+    assert "ST" not in c.MODEL.G_LOSS.CRITERIONS and isinstance(c.get_all_params(), str)
+    assert "ST" not in Config().MODEL.G_LOSS.CRITERIONS        # instances do not share dicts
+
+
+def test_parameter_trees_and_init_order_match_oracle():
+    from oracle import model as om
+    from srganst.config import Config
+    from srganst.model import Discriminator, Generator
+    cfg = Config()
+    torch.manual_seed(0)
+    G = Generator(cfg)
+    torch.manual_seed(0)
+    ref = om.init_generator_state()
+    sd = G.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(torch.equal(sd[k], ref[k]) for k in sd)
+    assert sum(p.numel() for p in G.parameters()) == 1547350
+    torch.manual_seed(0)
+    D = Discriminator(cfg)
+    torch.manual_seed(0)
+    refd = om.init_discriminator_state()
+    sdd = D.state_dict()
+    assert list(sdd.keys()) == list(refd.keys()) and all(torch.equal(sdd[k], refd[k]) for k in sdd)
+    assert sum(p.numel() for p in D.parameters()) == 23563649
+    cfg.DATA.GT_IMAGE_SIZE = 192                               # BASELINE configs[4]: classifier in-features 8C*(192/16)^2
+    assert Discriminator(cfg).classifier[0].in_features == 512 * 12 * 12
+
+
+def test_no_cpu_fallback():
+    from srganst import _abi
+    from srganst.config import Config
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+    cfg = Config()
+    cfg.MODEL.G_N_CHANNEL, cfg.MODEL.G_N_RCB, cfg.MODEL.D_N_CHANNEL = 8, 1, 4
+    with pytest.raises(_abi.HipPathError):
+        Generator(cfg)(torch.rand(1, 3, 8, 8))
+    with pytest.raises(_abi.HipPathError):
+        Discriminator(cfg)(torch.rand(1, 3, 96, 96))
+    with pytest.raises(_abi.HipPathError):
+        StructureTensorLoss()(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
+    with pytest.raises(_abi.HipPathError):
+        MSELoss()(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
+
+
+def test_load_state_dict_strips_compile_prefix():
+    from srganst.config import Config
+    from srganst.model import Generator
+    from srganst.utils import load_state_dict
+    cfg = Config()
+    cfg.MODEL.G_N_CHANNEL, cfg.MODEL.G_N_RCB = 8, 1
+    a, b = Generator(cfg), Generator(cfg)
+    compiled = {"_orig_mod." + k: v for k, v in a.state_dict().items()}          # reference utils.py:35-48
+    compiled["_orig_mod.conv3.weight"] = torch.zeros(1)                          # shape mismatch is dropped (utils.py:52-53)
+    load_state_dict(b, compiled)
+    for k in a.state_dict():
+        if k != "conv3.weight":
+            assert torch.equal(a.state_dict()[k], b.state_dict()[k]), k
+
+
+def test_bicubic_matches_reference_golden(golden):
+    from srganst.bicubic import Bicubic
+    g = golden("bicubic")
+    hr = T(g["hr_u8"]).float() / 255
+    out = Bicubic("cpu")(hr, scale=0.25)
+    assert out.shape == (1, 3, 24, 24) and torch.equal(out, T(g["lr"]))          # bit-exact on the 1/255 grid
+    step = torch.zeros(1, 3, 96, 96)
+    step[..., 48:] = 1.0
+    s = Bicubic("cpu")(step, scale=0.25)
+    assert torch.equal(s, T(g["step_lr"])) and float(s.min()) < 0 and float(s.max()) > 1     # not clamped
+
+
+def test_metrics_match_reference_golden(golden):
+    from srganst.utils import PSNR, SSIM, bgr2ycbcr, tensor2img
+    g = golden("metrics")
+    t2i = tensor2img(T(g["img"]))
+    assert t2i.dtype == np.uint8 and np.array_equal(t2i, g["tensor2img"])
+    y = bgr2ycbcr(t2i.astype(np.float32) / 255.0, only_y=True)
+    assert np.allclose(y, g["y"], rtol=0, atol=1e-6)
+    yb = bgr2ycbcr(g["img_b_u8"].astype(np.float32) / 255.0, only_y=True)
+    assert abs(PSNR(y * 255, yb * 255) - float(g["psnr"])) < 1e-6
+    # SSIM: cv2 is absent so the reference's own value cannot be produced here ("parity unpinned");
+    # check the restatement's invariants instead.
+    assert abs(SSIM(y * 255, y * 255) - 1.0) < 1e-12
+    s = SSIM(y * 255, yb * 255)
+    assert 0.0 < s < 1.0
+    from scipy.signal import correlate2d
+    from srganst.utils import _filter_valid, _gaussian_window
+    w = _gaussian_window()
+    assert np.allclose(_filter_valid(y.astype(np.float64), w), correlate2d(y.astype(np.float64), w, mode="valid"))
+
+
+def test_bucket_slices():
+    from srganst.dist import bucket_slices
+    assert bucket_slices([5, 5, 5, 5], 1) == [(0, 4)]
+    sl = bucket_slices([10, 1, 1, 30, 2], 2)
+    assert sl[0][0] == 0 and sl[-1][1] == 5 and all(a < b for a, b in sl)
+    assert [i for a, b in sl for i in range(a, b)] == list(range(5))
