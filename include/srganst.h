@@ -57,6 +57,14 @@ int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, cons
                    const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
                    int B, int H, int W, int Cin, int Cout, int stride, int ksize, int accumulate,
                    void* stream);
+/* weight gradient of the two 9x9 convs with a 3-channel side (Generator.conv1 / conv3, model.py:101,127):
+ * N = (kx, ch3) = 27 of 32 MFMA columns instead of 3.  kind 0 = conv3 (C->3), kind 1 = conv1 (3->C). */
+int sst_wgrad_c3_supported(int C, int ksize);
+int64_t sst_wgrad_c3_slab_floats(int B, int H, int W, int C);
+int sst_wgrad_c3(const float* big, const float* small, float* slab, float* dw, const float* in_slope,
+                 float in_slope_const, int in_act, int kind, int B, int H, int W, int C, int accumulate,
+                 void* stream);
+
 /* data-gradient of a 3x3 / stride-2 / pad-1 conv (Discriminator.features model.py:35,42,49,56): the input-gradient
  * pixels are split into 4 parity classes, each a dense 1x1 / 1x2 / 2x1 / 2x2 correlation over dy. */
 int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin);

@@ -86,35 +86,6 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
     const int nks = (cin_blk + 7) >> 3;
     const int nchunks = KK * nks;
     if (cb) __syncthreads();
-    // ---- stage the input patch for this channel block (zero padding stays zero: transform only in-image pixels)
-    for (int q = tid; q < ((a.dbg & 1) ? 0 : NP * 16); q += CONV_NT) {
-      const int p = q >> 4, c4 = (q & 15) * 4;
-      const int py = p / PW, px = p - py * PW;
-      const int iy = iy0 + py, ix = ix0 + px, c = c0 + c4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.Cin) {
-        const float* src = a.x + (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + c;
-        if (vec_ok) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (c + j < a.Cin) v[j] = src[j];
-        }
-        if (a.in_scale) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (c + j < a.Cin) v[j] = fmaf(v[j], a.in_scale[c + j], a.in_shift[c + j]);
-        }
-        if (a.in_act == ACT_SLOPE) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
-        }
-      }
-      *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = v;
-    }
-    __syncthreads();
-
     // ---- this wave's share of the K chunks (chunk = one tap x 8 input channels = 4 MFMAs).
     // The loop body is ONE basic block of 6 chunks with two register sets (ping-pong, prefetch distance 3
     // chunks) and no register moves, so hipcc keeps counted vmcnt waits.  A wave's chunk count is rounded
@@ -157,6 +128,54 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
       ++a_i;
       return v;
     };
+    // first B fragments go out BEFORE the patch is staged: their L2 latency hides behind the staging
+    f32x4 A0 = pf_load(), A1 = pf_load(), A2 = pf_load(), B0, B1, B2;
+
+    // ---- stage the input patch for this channel block (zero padding stays zero: transform only in-image pixels).
+    // A thread's channel quad is the same for all its patch pixels (CONV_NT % 16 == 0): scale/shift live in registers.
+    {
+      const int c4 = (tid & 15) * 4, c = c0 + c4;
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (a.in_scale) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < a.Cin) {
+            sc[j] = a.in_scale[c + j];
+            sh[j] = a.in_shift[c + j];
+          }
+      }
+      for (int p = tid >> 4; p < ((a.dbg & 1) ? 0 : NP); p += CONV_NT / 16) {
+        const int py = p / PW, px = p - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.Cin) {
+          const float* src = a.x + (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + c;
+          if (vec_ok) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (c + j < a.Cin) v[j] = src[j];
+          }
+          if (a.in_scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+          }
+          if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+          }
+          if (!vec_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (c + j >= a.Cin) v[j] = 0.f;
+          }
+        }
+        *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = v;
+      }
+    }
+    __syncthreads();
+
 #define SST_CHUNK(BUSE, BLOAD)                                                                         \
     {                                                                                                  \
       const f32x4 av = a_load();                                                                       \
@@ -165,7 +184,6 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
       BLOAD = pf_load();                                                                               \
     }
     if (nmine > 0 && !(a.dbg & 2)) {
-      f32x4 A0 = pf_load(), A1 = pf_load(), A2 = pf_load(), B0, B1, B2;
       for (int c = 0; c < nmine; c += 6) {
         SST_CHUNK(A0, B0)
         SST_CHUNK(A1, B1)

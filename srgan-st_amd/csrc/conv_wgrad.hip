@@ -49,17 +49,23 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int64_t m0 = m_begin; m0 < m_end; m0 += SUB) {
-    __syncthreads();
-    // ---- stage 64 pixels x 64 channels of X' (shifted by the tap) and of dY
-    for (int q = tid; q < SUB * 16; q += CONV_NT) {
+  // Register-staged software pipeline: the global loads of sub-tile t+1 are in flight while sub-tile t's
+  // 32 MFMAs run out of LDS (one register set, written to LDS after the barrier that retires the reads of t).
+  f32x4 rx[4], rd[4];
+  unsigned rvalid = 0;     // bit u: slot u holds an in-image pixel (padding must stay exactly zero)
+  auto stage_load = [&](int64_t m0) {
+    rvalid = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = tid + u * CONV_NT;
       const int p = q >> 4, c4 = (q & 15) * 4;
-      const int64_t m = m0 + p;
+      const unsigned m = (unsigned)m0 + p;          // M < 2^31 (checked on the host): 32-bit index math
       f32x4 xv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end) {
-        const int b = (int)(m / ((int64_t)a.Ho * a.Wo));
-        const int rem = (int)(m - (int64_t)b * a.Ho * a.Wo);
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      if (m < (unsigned)m_end) {
+        const unsigned hw = (unsigned)(a.Ho * a.Wo);
+        const int b = (int)(m / hw);
+        const unsigned rem = m - (unsigned)b * hw;
+        const int oy = (int)(rem / (unsigned)a.Wo), ox = (int)(rem - (unsigned)oy * a.Wo);
         const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
         const int c = ci0 + c4;
         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.Cin) {
@@ -71,20 +77,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
             for (int j = 0; j < 4; ++j)
               if (c + j < a.Cin) xv[j] = src[j];
           }
-          if (a.in_scale) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (c + j < a.Cin) xv[j] = fmaf(xv[j], a.in_scale[c + j], a.in_shift[c + j]);
-          }
-          if (a.in_act == ACT_SLOPE) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = xv[j] > 0.f ? xv[j] : xv[j] * slope;
-          }
-          if (!xvec) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (c + j >= a.Cin) xv[j] = 0.f;
-          }
+          rvalid |= 1u << u;
         }
         const int co = co0 + c4;
         if (co < a.Cout) {
@@ -98,10 +91,54 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
           }
         }
       }
-      *reinterpret_cast<f32x4*>(&sX[p * WLD + c4]) = xv;
-      *reinterpret_cast<f32x4*>(&sD[p * WLD + c4]) = dv;
+      rx[u] = xv;
+      rd[u] = dv;
     }
+  };
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};   // a thread's channel quad is fixed (CONV_NT % 16 == 0)
+  {
+    const int c = ci0 + (tid & 15) * 4;
+    if (a.in_scale) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < a.Cin) {
+          sc4[j] = a.in_scale[c + j];
+          sh4[j] = a.in_shift[c + j];
+        }
+    }
+  }
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = tid + u * CONV_NT;
+      const int p = q >> 4, c4 = (q & 15) * 4;
+      f32x4 xv = rx[u];
+      if ((rvalid >> u) & 1u) {
+        const int c = ci0 + c4;
+        if (a.in_scale) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xv[j] = fmaf(xv[j], sc4[j], sh4[j]);
+        }
+        if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xv[j] = xv[j] > 0.f ? xv[j] : xv[j] * slope;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j >= a.Cin) xv[j] = 0.f;
+      } else {
+        xv = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      *reinterpret_cast<f32x4*>(&sX[p * WLD + c4]) = xv;
+      *reinterpret_cast<f32x4*>(&sD[p * WLD + c4]) = rd[u];
+    }
+  };
+  if (m_begin < m_end) stage_load(m_begin);
+  for (int64_t m0 = m_begin; m0 < m_end; m0 += SUB) {
+    __syncthreads();                 // MFMAs of the previous sub-tile are done reading LDS
+    stage_store();
     __syncthreads();
+    if (m0 + SUB < m_end) stage_load(m0 + SUB);
     // ---- 32 MFMAs: K = 64 pixels, 2 per instruction (lane half lh picks the pixel of the pair)
 #pragma unroll 8
     for (int kk = 0; kk < SUB / 2; ++kk) {
@@ -120,17 +157,34 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci]
+// dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci]     (fixed chunk order: reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunk,
                                                            int KK, int Cout, int Cin, int accumulate) {
   const int64_t per_tap = (int64_t)Cout * Cin, total = per_tap * KK;
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int tap = (int)(i / per_tap);
-    const int64_t oc = i - (int64_t)tap * per_tap;   // co*Cin + ci
-    float t = 0.f;
-    for (int s = 0; s < nchunk; ++s) t += slab[(size_t)s * total + i];
-    float* d = dw + oc * KK + tap;
-    *d = accumulate ? *d + t : t;
+  if ((Cin & 3) == 0) {
+    const int64_t total4 = total >> 2;
+    for (int64_t i4 = blockIdx.x * 256ll + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+      const int64_t i = i4 << 2;
+      const int tap = (int)(i / per_tap);
+      const int64_t oc = i - (int64_t)tap * per_tap;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int s = 0; s < nchunk; ++s) t += *reinterpret_cast<const f32x4*>(slab + (size_t)s * total + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* d = dw + (oc + j) * KK + tap;
+        *d = accumulate ? *d + t[j] : t[j];
+      }
+    }
+  } else {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int tap = (int)(i / per_tap);
+      const int64_t oc = i - (int64_t)tap * per_tap;
+      float t = 0.f;
+      for (int s = 0; s < nchunk; ++s) t += slab[(size_t)s * total + i];
+      float* d = dw + oc * KK + tap;
+      *d = accumulate ? *d + t : t;
+    }
   }
 }
 
@@ -141,7 +195,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 SST_API int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int ksize) {
   const int64_t M = (int64_t)B * Ho * Wo;
   const int nblk = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-  int64_t want = (768 + ksize * ksize * nblk - 1) / (ksize * ksize * nblk);   // ~3 workgroups per CU
+  int64_t want = (320 + ksize * ksize * nblk - 1) / (ksize * ksize * nblk);   // ~1.2 workgroups per CU: keeps the slabs small
   int64_t maxc = (M + SUB - 1) / SUB;
   if (want > maxc) want = maxc;
   if (want < 1) want = 1;
@@ -162,6 +216,7 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
   a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
   const int64_t M = (int64_t)B * a.Ho * a.Wo;
+  SST_REQUIRE(M < (1ll << 31), "sst_conv_wgrad: too many pixels");
   const int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
   a.chunk_px = (int)(((M + nchunk - 1) / nchunk + SUB - 1) / SUB * SUB);
   const int KK = ksize * ksize;
@@ -169,7 +224,8 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   conv_wgrad_kernel<<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
   SST_LAUNCH_CHECK("conv_wgrad_kernel");
   const int64_t total = (int64_t)KK * Cout * Cin;
-  const int rb = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  const int64_t items = (Cin & 3) == 0 ? total / 4 : total;
+  const int rb = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
   wgrad_reduce_kernel<<<rb, 256, 0, sst_stream(stream)>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate);
   SST_LAUNCH_CHECK("wgrad_reduce_kernel");
   return SST_OK;

@@ -47,6 +47,9 @@ SIGNATURES = {
     "sst_pixel_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int64, c_int, P]),
     "sst_bce_logits": (c_int, [P, c_float, P, P, P, c_float, c_int, P]),
     "sst_weighted_sum": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, P, P, P]),
+    "sst_wgrad_c3_supported": (c_int, [c_int, c_int]),
+    "sst_wgrad_c3_slab_floats": (c_int64, [c_int, c_int, c_int, c_int]),
+    "sst_wgrad_c3": (c_int, [P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_s2_dgrad_packed_floats": (c_int64, [c_int, c_int]),
     "sst_conv_s2_dgrad_pack": (c_int, [P, P, c_int, c_int, P]),
     "sst_conv_s2_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -65,7 +65,8 @@ class _GraphedStep:
 class WarmupEngine:
     """reference warmup.py:14-96 without the data loader / logging / validation around the step."""
 
-    def __init__(self, config, generator, criterions=None, weights=None, use_graph=None, process_group=None):
+    def __init__(self, config, generator, criterions=None, weights=None, use_graph=None, process_group=None,
+                 adam_capturable=None):
         self.config = config
         self.G = generator
         self.criterions = criterions if criterions is not None else config.MODEL.G_LOSS.WARMUP_CRITERIONS
@@ -74,7 +75,8 @@ class WarmupEngine:
         self.world = sdist.world_size(process_group)
         use_graph = config.KERNEL.USE_GRAPH if use_graph is None else use_graph
         self.opt = make_adam(self.G.parameters(), config.SOLVER.G_BASE_LR, (config.SOLVER.G_BETA1, config.SOLVER.G_BETA2),
-                             config.SOLVER.G_EPS, config.SOLVER.G_WEIGHT_DECAY, capturable=use_graph)
+                             config.SOLVER.G_EPS, config.SOLVER.G_WEIGHT_DECAY,
+                             capturable=use_graph if adam_capturable is None else adam_capturable)
         self.gt = self.lr = None
         self.loss_values = OrderedDict()
         self.sr = None
@@ -125,7 +127,7 @@ class WarmupEngine:
 class TrainEngine:
     """reference train.py:16-164 without loaders / logging / validation around the step."""
 
-    def __init__(self, config, generator, discriminator, use_graph=None, process_group=None):
+    def __init__(self, config, generator, discriminator, use_graph=None, process_group=None, adam_capturable=None):
         from .loss import BCEWithLogitsLoss
         self.config = config
         self.G, self.D = generator, discriminator
@@ -133,8 +135,9 @@ class TrainEngine:
         self.world = sdist.world_size(process_group)
         use_graph = config.KERNEL.USE_GRAPH if use_graph is None else use_graph
         s = config.SOLVER
-        self.g_opt = make_adam(self.G.parameters(), s.G_BASE_LR, (s.G_BETA1, s.G_BETA2), s.G_EPS, s.G_WEIGHT_DECAY, use_graph)
-        self.d_opt = make_adam(self.D.parameters(), s.D_BASE_LR, (s.D_BETA1, s.D_BETA2), s.D_EPS, s.D_WEIGHT_DECAY, use_graph)
+        cap = use_graph if adam_capturable is None else adam_capturable
+        self.g_opt = make_adam(self.G.parameters(), s.G_BASE_LR, (s.G_BETA1, s.G_BETA2), s.G_EPS, s.G_WEIGHT_DECAY, cap)
+        self.d_opt = make_adam(self.D.parameters(), s.D_BASE_LR, (s.D_BETA1, s.D_BETA2), s.D_EPS, s.D_WEIGHT_DECAY, cap)
         self.adv = BCEWithLogitsLoss()                      # train.py:59
         self.real = 1.0 - config.EXP.LABEL_SMOOTHING        # train.py:113
         self.fake = 0.0                                     # train.py:114

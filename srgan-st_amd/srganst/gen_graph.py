@@ -98,7 +98,12 @@ def backward(module, params, sv, dsr, need_dx=False):
     # ---- conv3 + clamp
     u, slope, sr_pre = sv["last"]
     g3 = ops.clamp_bwd(dsr.contiguous(), sr_pre, dbias=grads["conv3.bias"])
-    ops.conv_wgrad(u, g3, grads["conv3.weight"], 9, 1, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
+    cout3 = p["conv3.weight"].shape[0]
+    fast9 = cout3 == 3 and sv["x3"].shape[-1] == 3 and ops.wgrad_c3_supported(C)
+    if fast9:
+        ops.wgrad_c3(u, g3, grads["conv3.weight"], 0, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
+    else:
+        ops.conv_wgrad(u, g3, grads["conv3.weight"], 9, 1, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
     g = ops.conv_fwd(g3, ops.pack_conv(p["conv3.weight"], 1), C, 9, 1)[0]          # d PReLU(u)
     # ---- up-sampling blocks, last to first
     for j in reversed(range(len(sv["ups"]))):
@@ -146,7 +151,10 @@ def backward(module, params, sv, dsr, need_dx=False):
     part = ops.bwd_reduce(dh, z1, g2=dskip, slope=a1, act=1)
     ops.bwd_finalize(part, n, dbeta=grads["conv1.0.bias"], dslope=grads["conv1.1.weight"])
     dz1 = ops.bwd_apply(dh, z1, g2=dskip, slope=a1, act=1)
-    ops.conv_wgrad(sv["x3"], dz1, grads["conv1.0.weight"], 9, 1)
+    if fast9:
+        ops.wgrad_c3(dz1, sv["x3"], grads["conv1.0.weight"], 1)
+    else:
+        ops.conv_wgrad(sv["x3"], dz1, grads["conv1.0.weight"], 9, 1)
     dx = None
     if need_dx:
         dx3 = ops.conv_fwd(dz1, ops.pack_conv(p["conv1.0.weight"], 1), sv["x3"].shape[-1], 9, 1)[0]

@@ -291,3 +291,21 @@ def flatten_act(y, scale, shift, slope, act=1):
     check(_abi.lib().sst_flatten_act(ptr(y), ptr(scale), ptr(shift), float(slope), int(act), ptr(flat), B, H * W, C,
                                      stream_ptr()), "sst_flatten_act")
     return flat
+
+
+def wgrad_c3(big, small, dw_out, kind, in_slope=None, in_slope_const=0.0, in_act=ACT_NONE, accumulate=False):
+    """Weight gradient of a 9x9 conv with a 3-channel side.  kind 0: conv3 (C->3): big = conv input, small = dY,
+    dw_out [3,C,9,9].  kind 1: conv1 (3->C): big = dY, small = conv input, dw_out [C,3,9,9]."""
+    B, H, W, C = big.shape
+    assert tuple(small.shape) == (B, H, W, 3)
+    assert tuple(dw_out.shape) == ((3, C, 9, 9) if kind == 0 else (C, 3, 9, 9))
+    slab = _f32(_abi.lib().sst_wgrad_c3_slab_floats(B, H, W, C), like=big)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_wgrad_c3(ptr(big), ptr(small), ptr(slab), ptr(dw_out), ptr(in_slope), float(in_slope_const), int(in_act),
+                                  kind, B, H, W, C, int(accumulate), stream_ptr()), "sst_wgrad_c3")
+    _prof_end(e0, "wgrad_c3_kernel+reduce", 2.0 * B * H * W * C * 3 * 81)
+    return dw_out
+
+
+def wgrad_c3_supported(C, ksize=9):
+    return bool(_abi.lib().sst_wgrad_c3_supported(C, ksize))

@@ -182,7 +182,9 @@ def test_gan_iteration_small_golden(golden):
 
 
 def test_train_engine_graph_equals_eager():
-    """hipGraph replay of the train step == eager step (same kernels, same order)."""
+    """hipGraph replay of the train step == eager step, bit for bit (same kernels, same order, same optimizer
+    code path: both runs use the device-side (capturable) fused Adam - the host-side variant rounds its bias
+    corrections differently (1e-7 relative), which GAN dynamics amplify within a few steps)."""
     from srganst.engine import TrainEngine
     from srganst.loss import MSELoss, StructureTensorLoss
     from srganst.model import Discriminator, Generator
@@ -194,7 +196,7 @@ def test_train_engine_graph_equals_eager():
         cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
         cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
         cfg.SOLVER.D_UPDATE_INTERVAL = 1
-        eng = TrainEngine(cfg, G, D, use_graph=use_graph)
+        eng = TrainEngine(cfg, G, D, use_graph=use_graph, adam_capturable=True)
         gen = torch.Generator().manual_seed(2)
         for _ in range(5):
             gt = torch.rand(4, 3, 96, 96, generator=gen).cuda()
@@ -206,8 +208,7 @@ def test_train_engine_graph_equals_eager():
     g1, d1, l1 = run(False)
     g2, d2, l2 = run(True)
     for k in g1:
-        assert torch.allclose(g1[k].float(), g2[k].float(), rtol=1e-4, atol=1e-5), k
+        assert torch.equal(g1[k], g2[k]), k
     for k in d1:
-        assert torch.allclose(d1[k].float(), d2[k].float(), rtol=1e-4, atol=1e-5), k
-    for k in l1:
-        assert abs(l1[k] - l2[k]) <= 1e-4 * abs(l1[k]) + 1e-7
+        assert torch.equal(d1[k], d2[k]), k
+    assert l1 == l2

@@ -200,3 +200,26 @@ def test_bn_residual_and_add(ops):
     out = ops.bn_residual(y.cuda(), sc.cuda(), sh.cuda(), res.cuda())
     assert torch.allclose(out.cpu(), y * sc + sh + res, rtol=1e-6, atol=1e-6)
     assert torch.equal(ops.add(y.cuda(), res.cuda()).cpu(), y + res)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64), (1, 13, 20, 8), (1, 96, 96, 64), (1, 7, 100, 16)])
+def test_wgrad_c3_both_kinds(ops, case):
+    """9x9 weight gradients with the (kx, 3ch) -> N folding, against autograd (conv3: C->3 with PReLU'd input; conv1: 3->C)."""
+    B, H, W, C = case
+    g = torch.Generator().manual_seed(31)
+    # conv3: y = conv9x9(prelu(u), w3)
+    u = torch.randn(B, C, H, W, generator=g)
+    w3 = torch.randn(3, C, 9, 9, generator=g, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(B, 3, H, W, generator=g)
+    F.conv2d(F.prelu(u.double(), torch.tensor([0.25], dtype=torch.float64)), w3, None, 1, 4).backward(dy.double())
+    dw = torch.zeros(3, C, 9, 9).cuda()
+    ops.wgrad_c3(nhwc(u).cuda(), nhwc(dy).cuda(), dw, 0, in_slope=torch.tensor([0.25]).cuda(), in_act=ops.ACT_SLOPE)
+    assert rel_err(dw.cpu(), w3.grad) < TOL
+    # conv1: y = conv9x9(x3, w1)
+    x3 = torch.randn(B, 3, H, W, generator=g)
+    w1 = torch.randn(C, 3, 9, 9, generator=g, dtype=torch.float64, requires_grad=True)
+    dz = torch.randn(B, C, H, W, generator=g)
+    F.conv2d(x3.double(), w1, None, 1, 4).backward(dz.double())
+    dw1 = torch.zeros(C, 3, 9, 9).cuda()
+    ops.wgrad_c3(nhwc(dz).cuda(), nhwc(x3).cuda(), dw1, 1)
+    assert rel_err(dw1.cpu(), w1.grad) < TOL
