@@ -45,6 +45,9 @@ int sst_st_loss_bwd(const float* sr, const float* gS, float* dsr, const float* s
  * stats: per-tile BatchNorm partials [sst_conv_mtiles][2][Cout] (sum, centred M2), stats_cnt [mtiles]. */
 int64_t sst_conv_packed_floats(int Cout, int Cin, int ksize);
 int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksize, int mode, void* stream);
+/* one launch for many tensors: jobs = device array of {const float* w; float* wp; int Cout, Cin, KK, mode;
+ * long long total, block_begin;} (48 bytes each; each workgroup packs 1024 floats) */
+int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, void* stream);
 int sst_conv_mtiles(int B, int Ho, int Wo);
 int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,
                  const float* in_scale, const float* in_shift, const float* in_slope,
@@ -86,6 +89,12 @@ int sst_bwd_reduce_blocks(int64_t R, int C);
 int sst_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale,
                    const float* shift, const float* slope, float slope_const, int act, float* partial,
                    int64_t R, int C, void* stream);
+/* reduce + finalize in one launch (last-arriving workgroup finalizes); counter: one zeroed word, left zero */
+int sst_bwd_reduce_finalize(const float* g, const float* g2, const float* y, const float* scale,
+                            const float* shift, const float* slope, float slope_const, int act,
+                            float* partial, int64_t R, int C, unsigned* counter, float n, const float* mean,
+                            const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
+                            float* cB, float* cC, float* dslope, int accumulate, void* stream);
 int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean,
                      const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
                      float* cB, float* cC, float* dslope, int accumulate, void* stream);

@@ -92,6 +92,78 @@ __global__ __launch_bounds__(NT) void bn_residual_kernel(const float* __restrict
   }
 }
 
+// Finalize of the backward reductions, executed by ONE workgroup of FT threads (either the separate
+// bwd_finalize_kernel or the last-arriving workgroup of bwd_reduce_kernel).  If mean != null (BatchNorm):
+// writes dgamma, dbeta and the coefficients of   dy = cA[c]*gz + cB[c]*y + cC[c]   else (bias-only layer)
+// dbeta = sum gz.  dslope (scalar) = sum_c partial[2] when dslope != null.  L lanes per channel split the
+// nblk partials; lane 0 of each channel combines them in fixed order.
+struct FinArgs {
+  const float* mean; const float* rstd; const float* gamma;
+  float* dgamma; float* dbeta; float* cA; float* cB; float* cC; float* dslope;
+  float n; int accumulate;
+};
+
+template <int FT, bool AGENT_LOADS>
+__device__ __forceinline__ void bwd_finalize_body(const float* __restrict__ partial, int nblk, int C, const FinArgs& f,
+                                                  float* sm /* [3][FT] */, float* red /* [FT/64] */) {
+  float al = 0.f;
+  const int L = C >= FT ? 1 : FT / C;
+  for (int cbase = 0; cbase < C; cbase += FT / L) {
+    const int c = cbase + (int)threadIdx.x / L, q = threadIdx.x % L;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+      for (int b = q; b < nblk; b += L) {
+        const float* p = partial + (size_t)b * 3 * C + c;
+        if (AGENT_LOADS) {
+          s0 += load_agent(p);
+          s1 += load_agent(p + C);
+          s2 += load_agent(p + 2 * C);
+        } else {
+          s0 += p[0];
+          s1 += p[C];
+          s2 += p[2 * C];
+        }
+      }
+    }
+    __syncthreads();
+    sm[threadIdx.x] = s0;
+    sm[FT + threadIdx.x] = s1;
+    sm[2 * FT + threadIdx.x] = s2;
+    __syncthreads();
+    if (c < C && q == 0) {
+      s0 = s1 = s2 = 0.f;
+      for (int i = 0; i < L; ++i) {
+        s0 += sm[threadIdx.x + i];
+        s1 += sm[FT + threadIdx.x + i];
+        s2 += sm[2 * FT + threadIdx.x + i];
+      }
+      al += s2;
+      if (f.mean) {
+        const float mu = f.mean[c], rs = f.rstd[c], ga = f.gamma[c];
+        const float sgh = rs * (s1 - mu * s0);   // sum gz * yhat
+        const float m1 = s0 / f.n, m2 = sgh / f.n;
+        if (f.accumulate) {
+          f.dgamma[c] += sgh;
+          f.dbeta[c] += s0;
+        } else {
+          f.dgamma[c] = sgh;
+          f.dbeta[c] = s0;
+        }
+        const float a = ga * rs;
+        f.cA[c] = a;
+        f.cB[c] = -a * rs * m2;
+        f.cC[c] = -a * m1 + a * rs * mu * m2;
+      } else if (f.dbeta) {
+        if (f.accumulate) f.dbeta[c] += s0; else f.dbeta[c] = s0;
+      }
+    }
+  }
+  al = block_sum<FT>(al, red);
+  if (f.dslope && threadIdx.x == 0) {
+    if (f.accumulate) f.dslope[0] += al; else f.dslope[0] = al;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward reductions over rows.  With z = y*scale+shift (or z = y when scale == null) and
 // gz = g * (act ? (z > 0 ? 1 : slope) : 1):
@@ -101,8 +173,9 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ slope_p,
                                                         float slope_c, int act, float* __restrict__ partial, int64_t R,
-                                                        int C, int rows_per_block) {
-  extern __shared__ float sm[];  // [rowlanes][3][C]
+                                                        int C, int rows_per_block, unsigned* __restrict__ counter, FinArgs fin) {
+  extern __shared__ float sm[];  // [rowlanes][3][C]   (>= 3*NT + NT/64 floats when the finalize is fused)
+  __shared__ unsigned s_last;
   const int c4n = C >> 2;
   const int rowlanes = NT / c4n;
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
@@ -150,70 +223,30 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
     for (int q = 0; q < rowlanes; ++q) t += sm[(size_t)q * 3 * C + i];
     partial[(size_t)blockIdx.x * 3 * C + i] = t;
   }
+  if (counter) {
+    // fused finalize: every storing wave drains its stores, the workgroup meets, one lane releases + takes a
+    // ticket (agent scope); the last arriver acquires and reduces all partials in fixed order (cdna guide G16).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (publish_and_ticket(counter) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+      if (threadIdx.x == 0) acquire_after_ticket();
+      __syncthreads();
+      bwd_finalize_body<NT, true>(partial, gridDim.x, C, fin, sm, sm + 3 * NT);
+      if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // Finalize of the above.  If mean != null (BatchNorm): writes dgamma, dbeta and the coefficients of
 //   dy = cA[c]*gz + cB[c]*y + cC[c]          (gz as defined above)
 // else (no BN: bias-only layer): writes dbias = sum gz.   dslope (scalar) += sum_c partial[2] when dslope != null.
-constexpr int FT = 1024;   // threads of the (single-workgroup) finalize kernel
-__global__ __launch_bounds__(FT) void bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float n,
-                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, float* __restrict__ cA,
-                                                          float* __restrict__ cB, float* __restrict__ cC,
-                                                          float* __restrict__ dslope, int accumulate) {
-  __shared__ float sm[3][FT];
+constexpr int FT = 1024;   // threads of the stand-alone finalize kernel
+__global__ __launch_bounds__(FT) void bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f) {
+  __shared__ float sm[3 * FT];
   __shared__ float red[FT / 64];
-  float al = 0.f;
-  // L lanes per channel split the nblk partials; lane 0 of each channel combines them in fixed order
-  const int L = C >= FT ? 1 : FT / C;
-  for (int cbase = 0; cbase < C; cbase += FT / L) {
-    const int c = cbase + (int)threadIdx.x / L, q = threadIdx.x % L;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-      for (int b = q; b < nblk; b += L) {
-        s0 += partial[(size_t)b * 3 * C + c];
-        s1 += partial[(size_t)b * 3 * C + C + c];
-        s2 += partial[(size_t)b * 3 * C + 2 * C + c];
-      }
-    }
-    __syncthreads();
-    sm[0][threadIdx.x] = s0;
-    sm[1][threadIdx.x] = s1;
-    sm[2][threadIdx.x] = s2;
-    __syncthreads();
-    if (c < C && q == 0) {
-      s0 = s1 = s2 = 0.f;
-      for (int i = 0; i < L; ++i) {
-        s0 += sm[0][threadIdx.x + i];
-        s1 += sm[1][threadIdx.x + i];
-        s2 += sm[2][threadIdx.x + i];
-      }
-      al += s2;
-      if (mean) {
-        const float mu = mean[c], rs = rstd[c], ga = gamma[c];
-        const float sgh = rs * (s1 - mu * s0);   // sum gz * yhat
-        const float m1 = s0 / n, m2 = sgh / n;
-        if (accumulate) {
-          dgamma[c] += sgh;
-          dbeta[c] += s0;
-        } else {
-          dgamma[c] = sgh;
-          dbeta[c] = s0;
-        }
-        const float a = ga * rs;
-        cA[c] = a;
-        cB[c] = -a * rs * m2;
-        cC[c] = -a * m1 + a * rs * mu * m2;
-      } else if (dbeta) {
-        if (accumulate) dbeta[c] += s0; else dbeta[c] = s0;
-      }
-    }
-  }
-  al = block_sum<FT>(al, red);
-  if (dslope && threadIdx.x == 0) {
-    if (accumulate) dslope[0] += al; else dslope[0] = al;
-  }
+  bwd_finalize_body<FT, false>(partial, nblk, C, f, sm, red);
 }
 
 // dy = cA*gz + cB*y + cC  (BatchNorm input gradient), or dy = gz when cA == null (activation only).
@@ -316,20 +349,42 @@ SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
   return (int)(nb < 1 ? 1 : nb);
 }
 
-SST_API int sst_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
-                           const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
-                           void* stream) {
+static int launch_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                             const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
+                             unsigned* counter, const FinArgs& fin, void* stream) {
   SST_REQUIRE(g && y && partial && R > 0 && C >= 4 && (C & 3) == 0 && C <= 1024, "sst_bwd_reduce: bad argument (C=%d)", C);
   SST_REQUIRE(NT % (C / 4) == 0 || C / 4 > NT, "sst_bwd_reduce: C/4 must divide %d", NT);
   SST_REQUIRE(C / 4 <= NT, "sst_bwd_reduce: C too large");
   const int nblk = sst_bwd_reduce_blocks(R, C);
   const int rpb = (int)((R + nblk - 1) / nblk);
   const int rowlanes = NT / (C / 4);
-  const size_t smem = (size_t)rowlanes * 3 * C * sizeof(float);
+  size_t smem = (size_t)rowlanes * 3 * C * sizeof(float);
+  const size_t fin_smem = (size_t)(3 * NT + NT / 64) * sizeof(float);
+  if (counter && smem < fin_smem) smem = fin_smem;
   bwd_reduce_kernel<<<nblk, NT, smem, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C,
-                                                             rpb);
+                                                             rpb, counter, fin);
   SST_LAUNCH_CHECK("bwd_reduce_kernel");
   return SST_OK;
+}
+
+SST_API int sst_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                           const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
+                           void* stream) {
+  FinArgs fin = {};
+  return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, nullptr, fin, stream);
+}
+
+// bwd_reduce + bwd_finalize in one launch (the last-arriving workgroup finalizes).  counter: one zeroed word,
+// left zero again by the kernel.
+SST_API int sst_bwd_reduce_finalize(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                                    const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
+                                    unsigned* counter, float n, const float* mean, const float* rstd, const float* gamma,
+                                    float* dgamma, float* dbeta, float* cA, float* cB, float* cC, float* dslope,
+                                    int accumulate, void* stream) {
+  SST_REQUIRE(counter, "sst_bwd_reduce_finalize: counter");
+  SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_reduce_finalize: BN mode needs all BN pointers");
+  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
+  return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, counter, fin, stream);
 }
 
 SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean, const float* rstd,
@@ -337,8 +392,8 @@ SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, con
                              float* dslope, int accumulate, void* stream) {
   SST_REQUIRE(partial && nblk > 0 && C > 0, "sst_bwd_finalize: bad argument");
   SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize: BN mode needs all BN pointers");
-  bwd_finalize_kernel<<<1, FT, 0, sst_stream(stream)>>>(partial, nblk, C, n, mean, rstd, gamma, dgamma, dbeta, cA, cB, cC,
-                                                        dslope, accumulate);
+  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
+  bwd_finalize_kernel<<<1, FT, 0, sst_stream(stream)>>>(partial, nblk, C, fin);
   SST_LAUNCH_CHECK("bwd_finalize_kernel");
   return SST_OK;
 }

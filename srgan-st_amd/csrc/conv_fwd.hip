@@ -345,6 +345,46 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
   }
 }
 
+// Multi-tensor variant: ONE launch packs every conv weight of a network (job table in device memory).
+struct PackJob {
+  const float* w;
+  float* wp;
+  int Cout, Cin, KK, mode;
+  long long total;
+  long long block_begin;    // first workgroup of this job (each workgroup packs 1024 floats)
+};
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;                       // last job with block_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackJob jb = jobs[lo];
+  const int O = jb.mode ? jb.Cin : jb.Cout, I = jb.mode ? jb.Cout : jb.Cin;
+  const int ncb = (I + 63) / 64;
+  const long long base = ((long long)blockIdx.x - jb.block_begin) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long idx = base + u * 256 + threadIdx.x;
+    if (idx >= jb.total) break;
+    const int j = idx & 3, l = (idx >> 2) & 63, ks = (idx >> 8) & 7;
+    long long rest = idx >> 11;
+    const int tap = rest % jb.KK;
+    rest /= jb.KK;
+    const int cbk = rest % ncb;
+    const int of = rest / ncb;
+    const int o = of * 32 + (l & 31), i = cbk * 64 + ks * 8 + (l >> 5) * 4 + j;
+    float v = 0.f;
+    if (of < (O + 31) / 32 && o < O && i < I) {
+      if (jb.mode == 0)
+        v = jb.w[((size_t)o * jb.Cin + i) * jb.KK + tap];
+      else
+        v = jb.w[((size_t)i * jb.Cin + o) * jb.KK + (jb.KK - 1 - tap)];
+    }
+    jb.wp[idx] = v;
+  }
+}
+
 // Data-gradient of a 3x3 / stride-2 / pad-1 conv, parity class (py,px) of the input-gradient pixel (iy,ix) =
 // (2a+py, 2b+px):  dX[iy,ix,ci] = sum over taps (jy,jx) of the class, co:  dY[a+jy, b+jx, co] * W[co][ci][ky][kx]
 // with ky = py ? (jy ? 0 : 2) : 1 (same for kx).  Class c = 2*py+px has (1+py)*(1+px) taps; the 4 classes are
@@ -391,6 +431,15 @@ SST_API int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksiz
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   pack_conv_kernel<<<blocks, 256, 0, sst_stream(stream)>>>(w, wp, Cout, Cin, ksize * ksize, mode, total);
   SST_LAUNCH_CHECK("pack_conv_kernel");
+  return SST_OK;
+}
+
+// jobs: device array of {w, wp, Cout, Cin, KK, mode, total, block_begin} (8 x 8 bytes each, see srganst/ops.py)
+SST_API int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, void* stream) {
+  SST_REQUIRE(jobs && njobs > 0 && total_blocks > 0, "sst_conv_pack_multi: bad argument");
+  static_assert(sizeof(PackJob) == 48, "PackJob layout");
+  pack_multi_kernel<<<total_blocks, 256, 0, sst_stream(stream)>>>(reinterpret_cast<const PackJob*>(jobs), njobs);
+  SST_LAUNCH_CHECK("pack_multi_kernel");
   return SST_OK;
 }
 

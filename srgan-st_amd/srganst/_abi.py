@@ -24,6 +24,9 @@ SIGNATURES = {
     "sst_st_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     "sst_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
     "sst_conv_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_pack_multi": (c_int, [P, c_int, c_int, P]),
+    "sst_bwd_reduce_finalize": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P, c_float, P, P, P, P, P, P, P, P,
+                                        P, c_int, P]),
     "sst_conv_mtiles": (c_int, [c_int, c_int, c_int]),
     "sst_conv_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -17,15 +17,25 @@ LRELU = 0.2
 PLAN = [(0, None, 1), (2, 3, 2), (5, 6, 1), (8, 9, 2), (11, 12, 1), (14, 15, 2), (17, 18, 1), (20, 21, 2)]
 
 
+def _packs(module, p, mode):
+    cache = module.__dict__.setdefault("_hip_cache", {})
+    names = [f"features.{ci}.weight" for ci, _, s in PLAN if mode == 0 or s == 1]
+    ws = [p[n] for n in names]
+    return dict(zip(names, ops.packed_weights(cache, ("pack", mode), ws, [mode] * len(ws))))
+
+
 def forward(module, x, p, training):
     sv = {"layers": []}
+    wp = _packs(module, p, 0)
+    if training:
+        ops.flatten_bn_counters(module).add_(1)
     x3 = ops.transpose(x.contiguous(), to_nchw=False)
     h, scale, shift, act = x3, None, None, 0
     for ci, bi, stride in PLAN:
         w = p[f"features.{ci}.weight"]
         cout = w.shape[0]
         bias = p.get(f"features.{ci}.bias")
-        y, _, st, cnt = ops.conv_fwd(h, ops.pack_conv(w), cout, 3, stride, bias=bias, in_scale=scale, in_shift=shift,
+        y, _, st, cnt = ops.conv_fwd(h, wp[f"features.{ci}.weight"], cout, 3, stride, bias=bias, in_scale=scale, in_shift=shift,
                                      in_slope_const=LRELU, in_act=act, want_stats=(bi is not None and training))
         rec = {"x": h, "x_scale": scale, "x_shift": shift, "x_act": act, "y": y, "ci": ci, "bi": bi, "stride": stride}
         if bi is not None:
@@ -33,7 +43,6 @@ def forward(module, x, p, training):
             g, b = p[f"features.{bi}.weight"], p[f"features.{bi}.bias"]
             if training:
                 mean, rstd, scale, shift = ops.bn_finalize(st, cnt, g, b, bn.running_mean, bn.running_var)
-                bn.num_batches_tracked.add_(1)
                 rec["mean"], rec["rstd"] = mean, rstd
             else:
                 scale, shift = ops.bn_eval_affine(g, b, bn.running_mean, bn.running_var)
@@ -67,21 +76,23 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
     B, H, W, C = last["y"].shape
     g = ops.linear_dgrad(dh1, p["classifier.0.weight"], nhwc=(C, H * W)).view(B, H, W, C)   # d LReLU(BN(y_last)) in NHWC
     dx = None
+    wd = _packs(module, p, 1)
     for li in reversed(range(len(sv["layers"]))):
         r = sv["layers"][li]
         y = r["y"]
         n = y.numel() // y.shape[-1]
         ci, bi = r["ci"], r["bi"]
         w = p[f"features.{ci}.weight"]
-        part = ops.bwd_reduce(g, y, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1)
         if bi is not None:
             gam = p[f"features.{bi}.weight"]
             dg = G(f"features.{bi}.weight") if wg else torch.empty_like(gam)
             db = G(f"features.{bi}.bias") if wg else torch.empty_like(gam)
-            cA, cB, cC = ops.bwd_finalize(part, n, r["mean"], r["rstd"], gam, dg, db)
+            cA, cB, cC = ops.bwd_reduce_finalize(g, y, n, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1,
+                                                 mean=r["mean"], rstd=r["rstd"], gamma=gam, dgamma=dg, dbeta=db)
             dy = ops.bwd_apply(g, y, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1, cA=cA, cB=cB, cC=cC)
         else:
-            ops.bwd_finalize(part, n, dbeta=G(f"features.{ci}.bias") if wg else None)
+            if wg:
+                ops.bwd_reduce_finalize(g, y, n, slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"))
             dy = ops.bwd_apply(g, y, slope_const=LRELU, act=1)
         if wg:
             ops.conv_wgrad(r["x"], dy, G(f"features.{ci}.weight"), 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
@@ -90,7 +101,7 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
             break
         xin = r["x"]
         if r["stride"] == 1:
-            g = ops.conv_fwd(dy, ops.pack_conv(w, 1), w.shape[1], 3, 1)[0]
+            g = ops.conv_fwd(dy, wd[f"features.{ci}.weight"], w.shape[1], 3, 1)[0]
         else:
             g = ops.conv_s2_dgrad(dy, ops.pack_conv_s2_dgrad(w), xin.shape[1], xin.shape[2], w.shape[1])
         if li == 0:

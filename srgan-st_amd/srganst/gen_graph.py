@@ -30,13 +30,34 @@ def _bn_buffers(bn, training):
     return (bn.running_mean, bn.running_var) if training else (None, None)
 
 
+def _conv_names(module):
+    names = ["conv1.0.weight"]
+    for i in range(len(module.trunk)):
+        names += [f"trunk.{i}.rcb.0.weight", f"trunk.{i}.rcb.3.weight"]
+    names.append("conv2.0.weight")
+    names += [f"upsampling.{j}.upsample_block.0.weight" for j in range(len(module.upsampling))]
+    names.append("conv3.weight")
+    return names
+
+
+def _packs(module, p, mode):
+    """name -> packed weight (mode 0 forward / mode 1 data-gradient); one multi-tensor launch."""
+    cache = module.__dict__.setdefault("_hip_cache", {})
+    names = _conv_names(module)
+    ws = [p[n] for n in names]
+    return dict(zip(names, ops.packed_weights(cache, ("pack", mode), ws, [mode] * len(ws))))
+
+
 def forward(module, x, params, need_grad):
     p = _P(module, params)
     training = module.training
     sv = {}                                       # saved for backward
     C = p["conv1.0.weight"].shape[0]
+    wp = _packs(module, p, 0)
+    if training:
+        ops.flatten_bn_counters(module).add_(1)
     x3 = ops.transpose(x.contiguous(), to_nchw=False)                                  # [B,h,w,3]
-    z1, _, _, _ = ops.conv_fwd(x3, ops.pack_conv(p["conv1.0.weight"]), C, 9, 1, bias=p["conv1.0.bias"])
+    z1, _, _, _ = ops.conv_fwd(x3, wp["conv1.0.weight"], C, 9, 1, bias=p["conv1.0.bias"])
     a1 = p["conv1.1.weight"]
     sv["x3"], sv["z1"] = x3, z1
 
@@ -44,7 +65,6 @@ def forward(module, x, params, need_grad):
         if training:
             mean, rstd, scale, shift = ops.bn_finalize(stats, cnt, p[pre + ".weight"], p[pre + ".bias"],
                                                        bn.running_mean, bn.running_var)
-            bn.num_batches_tracked.add_(1)
             return mean, rstd, scale, shift
         scale, shift = ops.bn_eval_affine(p[pre + ".weight"], p[pre + ".bias"], bn.running_mean, bn.running_var)
         return None, None, scale, shift
@@ -54,17 +74,17 @@ def forward(module, x, params, need_grad):
     for i, blk in enumerate(module.trunk):
         pre = f"trunk.{i}.rcb"
         first = i == 0
-        y1, _, st, cnt = ops.conv_fwd(h, ops.pack_conv(p[pre + ".0.weight"]), C, 3, 1,
+        y1, _, st, cnt = ops.conv_fwd(h, wp[pre + ".0.weight"], C, 3, 1,
                                       in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0,
                                       want_stats=training)
         m1, r1, s1, t1 = bn_affine(blk.rcb[1], pre + ".1", st, cnt)
-        y2, _, st, cnt = ops.conv_fwd(y1, ops.pack_conv(p[pre + ".3.weight"]), C, 3, 1, in_scale=s1, in_shift=t1,
+        y2, _, st, cnt = ops.conv_fwd(y1, wp[pre + ".3.weight"], C, 3, 1, in_scale=s1, in_shift=t1,
                                       in_slope=p[pre + ".2.weight"], in_act=ACT_SLOPE, want_stats=training)
         m2, r2, s2, t2 = bn_affine(blk.rcb[4], pre + ".4", st, cnt)
         h_next = ops.bn_residual(y2, s2, t2, h, a1 if first else None)
         blocks.append((h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2))
         h = h_next
-    y3, _, st, cnt = ops.conv_fwd(h, ops.pack_conv(p["conv2.0.weight"]), C, 3, 1, want_stats=training)
+    y3, _, st, cnt = ops.conv_fwd(h, wp["conv2.0.weight"], C, 3, 1, want_stats=training)
     m3, r3, s3, t3 = bn_affine(module.conv2[1], "conv2.1", st, cnt)
     u = ops.bn_residual(y3, s3, t3, z1, a1)
     sv["blocks"], sv["h_last"], sv["conv2"] = blocks, h, (y3, m3, r3, s3, t3)
@@ -72,13 +92,13 @@ def forward(module, x, params, need_grad):
     slope = None
     for j, _ in enumerate(module.upsampling):
         pre = f"upsampling.{j}.upsample_block"
-        us, _, _, _ = ops.conv_fwd(u, ops.pack_conv(p[pre + ".0.weight"]), 4 * C, 3, 1, bias=p[pre + ".0.bias"],
+        us, _, _, _ = ops.conv_fwd(u, wp[pre + ".0.weight"], 4 * C, 3, 1, bias=p[pre + ".0.bias"],
                                    in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0, out_mode=OUT_SHUFFLE)
         ups.append((u, slope, us))
         u, slope = us, p[pre + ".2.weight"]
     sv["ups"] = ups
     cout = p["conv3.weight"].shape[0]
-    sr, sr_pre, _, _ = ops.conv_fwd(u, ops.pack_conv(p["conv3.weight"]), cout, 9, 1, bias=p["conv3.bias"], in_slope=slope,
+    sr, sr_pre, _, _ = ops.conv_fwd(u, wp["conv3.weight"], cout, 9, 1, bias=p["conv3.bias"], in_slope=slope,
                                     in_act=ACT_SLOPE if slope is not None else 0, out_mode=OUT_NCHW_CLAMP,
                                     want_pre=need_grad)
     sv["last"] = (u, slope, sr_pre)
@@ -91,6 +111,7 @@ def backward(module, params, sv, dsr, need_dx=False):
     grads = {n: torch.empty_like(t) for n, t in zip(module._names, params)}
     C = p["conv1.0.weight"].shape[0]
     a1 = p["conv1.1.weight"]
+    wd = _packs(module, p, 1)
 
     def rows(t):
         return t.numel() // t.shape[-1]
@@ -104,52 +125,49 @@ def backward(module, params, sv, dsr, need_dx=False):
         ops.wgrad_c3(u, g3, grads["conv3.weight"], 0, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
     else:
         ops.conv_wgrad(u, g3, grads["conv3.weight"], 9, 1, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
-    g = ops.conv_fwd(g3, ops.pack_conv(p["conv3.weight"], 1), C, 9, 1)[0]          # d PReLU(u)
+    g = ops.conv_fwd(g3, wd["conv3.weight"], C, 9, 1)[0]          # d PReLU(u)
     # ---- up-sampling blocks, last to first
     for j in reversed(range(len(sv["ups"]))):
         pre = f"upsampling.{j}.upsample_block"
         u_in, slope_in, us = sv["ups"][j]
         sl = p[pre + ".2.weight"]
-        part = ops.bwd_reduce(g, us, slope=sl, act=1)
-        ops.bwd_finalize(part, rows(us), dslope=grads[pre + ".2.weight"])
+        ops.bwd_reduce_finalize(g, us, rows(us), slope=sl, act=1, dslope=grads[pre + ".2.weight"])
         du = ops.bwd_apply(g, us, slope=sl, act=1, unshuffle=True)                  # [B,h,w,4C] pre-shuffle grad
-        part = ops.bwd_reduce(du, du)
-        ops.bwd_finalize(part, rows(du), dbeta=grads[pre + ".0.bias"])
+        ops.bwd_reduce_finalize(du, du, rows(du), dbeta=grads[pre + ".0.bias"])
         ops.conv_wgrad(u_in, du, grads[pre + ".0.weight"], 3, 1, in_slope=slope_in,
                        in_act=ACT_SLOPE if slope_in is not None else 0)
-        g = ops.conv_fwd(du, ops.pack_conv(p[pre + ".0.weight"], 1), C, 3, 1)[0]    # d (input of the up-conv)
+        g = ops.conv_fwd(du, wd[pre + ".0.weight"], C, 3, 1)[0]    # d (input of the up-conv)
     # ---- u = BN(conv2(h_last)) + PReLU(z1)
     y3, m3, r3, s3, t3 = sv["conv2"]
     n = rows(y3)
-    part = ops.bwd_reduce(g, y3, scale=s3, shift=t3)
-    cA, cB, cC = ops.bwd_finalize(part, n, m3, r3, p["conv2.1.weight"], grads["conv2.1.weight"], grads["conv2.1.bias"])
+    cA, cB, cC = ops.bwd_reduce_finalize(g, y3, n, scale=s3, shift=t3, mean=m3, rstd=r3, gamma=p["conv2.1.weight"],
+                                         dgamma=grads["conv2.1.weight"], dbeta=grads["conv2.1.bias"])
     dy3 = ops.bwd_apply(g, y3, cA=cA, cB=cB, cC=cC)
     ops.conv_wgrad(sv["h_last"], dy3, grads["conv2.0.weight"], 3, 1,
                    in_slope=a1 if not sv["blocks"] else None, in_act=ACT_SLOPE if not sv["blocks"] else 0)
     dskip = g
-    dh = ops.conv_fwd(dy3, ops.pack_conv(p["conv2.0.weight"], 1), C, 3, 1)[0]
+    dh = ops.conv_fwd(dy3, wd["conv2.0.weight"], C, 3, 1)[0]
     # ---- residual blocks, last to first
     for i in reversed(range(len(sv["blocks"]))):
         pre = f"trunk.{i}.rcb"
         first = i == 0
         h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2 = sv["blocks"][i]
         sl = p[pre + ".2.weight"]
-        part = ops.bwd_reduce(dh, y2, scale=s2, shift=t2)
-        cA, cB, cC = ops.bwd_finalize(part, n, m2, r2, p[pre + ".4.weight"], grads[pre + ".4.weight"], grads[pre + ".4.bias"])
+        cA, cB, cC = ops.bwd_reduce_finalize(dh, y2, n, scale=s2, shift=t2, mean=m2, rstd=r2, gamma=p[pre + ".4.weight"],
+                                             dgamma=grads[pre + ".4.weight"], dbeta=grads[pre + ".4.bias"])
         dy2 = ops.bwd_apply(dh, y2, cA=cA, cB=cB, cC=cC)
         ops.conv_wgrad(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
-        dp1 = ops.conv_fwd(dy2, ops.pack_conv(p[pre + ".3.weight"], 1), C, 3, 1)[0]
-        part = ops.bwd_reduce(dp1, y1, scale=s1, shift=t1, slope=sl, act=1)
-        cA, cB, cC = ops.bwd_finalize(part, n, m1, r1, p[pre + ".1.weight"], grads[pre + ".1.weight"], grads[pre + ".1.bias"],
-                                      dslope=grads[pre + ".2.weight"])
+        dp1 = ops.conv_fwd(dy2, wd[pre + ".3.weight"], C, 3, 1)[0]
+        cA, cB, cC = ops.bwd_reduce_finalize(dp1, y1, n, scale=s1, shift=t1, slope=sl, act=1, mean=m1, rstd=r1,
+                                             gamma=p[pre + ".1.weight"], dgamma=grads[pre + ".1.weight"],
+                                             dbeta=grads[pre + ".1.bias"], dslope=grads[pre + ".2.weight"])
         dy1 = ops.bwd_apply(dp1, y1, scale=s1, shift=t1, slope=sl, act=1, cA=cA, cB=cB, cC=cC)
         ops.conv_wgrad(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None,
                        in_act=ACT_SLOPE if first else 0)
-        dh = ops.conv_fwd(dy1, ops.pack_conv(p[pre + ".0.weight"], 1), C, 3, 1, residual=dh)[0]
+        dh = ops.conv_fwd(dy1, wd[pre + ".0.weight"], C, 3, 1, residual=dh)[0]
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
-    part = ops.bwd_reduce(dh, z1, g2=dskip, slope=a1, act=1)
-    ops.bwd_finalize(part, n, dbeta=grads["conv1.0.bias"], dslope=grads["conv1.1.weight"])
+    ops.bwd_reduce_finalize(dh, z1, n, g2=dskip, slope=a1, act=1, dbeta=grads["conv1.0.bias"], dslope=grads["conv1.1.weight"])
     dz1 = ops.bwd_apply(dh, z1, g2=dskip, slope=a1, act=1)
     if fast9:
         ops.wgrad_c3(dz1, sv["x3"], grads["conv1.0.weight"], 1)
@@ -157,7 +175,7 @@ def backward(module, params, sv, dsr, need_dx=False):
         ops.conv_wgrad(sv["x3"], dz1, grads["conv1.0.weight"], 9, 1)
     dx = None
     if need_dx:
-        dx3 = ops.conv_fwd(dz1, ops.pack_conv(p["conv1.0.weight"], 1), sv["x3"].shape[-1], 9, 1)[0]
+        dx3 = ops.conv_fwd(dz1, wd["conv1.0.weight"], sv["x3"].shape[-1], 9, 1)[0]
         dx = ops.transpose(dx3, to_nchw=True)
     return [grads[n] for n in module._names], dx
 

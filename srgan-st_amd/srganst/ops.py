@@ -309,3 +309,89 @@ def wgrad_c3(big, small, dw_out, kind, in_slope=None, in_slope_const=0.0, in_act
 
 def wgrad_c3_supported(C, ksize=9):
     return bool(_abi.lib().sst_wgrad_c3_supported(C, ksize))
+
+
+# ------------------------------------------------------------------------------------------------
+class PackPlan:
+    """All conv weights of a network packed by ONE kernel launch (sst_conv_pack_multi).  The job table and the
+    packed buffers are persistent, so the launch is graph-capturable; rebuild when a parameter moves."""
+
+    def __init__(self, weights, modes):
+        dev = weights[0].device
+        self.ptrs = tuple(w.data_ptr() for w in weights)
+        self.out, rows, blk = [], [], 0
+        for w, m in zip(weights, modes):
+            cout, cin, k, _ = w.shape
+            o, i = (cin, cout) if m else (cout, cin)
+            n = _abi.lib().sst_conv_packed_floats(o, i, k)
+            wp = torch.empty(n, device=dev, dtype=torch.float32)
+            self.out.append(wp)
+            rows.append([w.data_ptr(), wp.data_ptr(), cout | (cin << 32), (k * k) | (int(m) << 32), n, blk])
+            blk += (n + 1023) // 1024
+        self.blocks = blk
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+
+    def matches(self, weights):
+        return self.ptrs == tuple(w.data_ptr() for w in weights)
+
+    def run(self):
+        check(_abi.lib().sst_conv_pack_multi(ptr(self.table), len(self.out), self.blocks, stream_ptr()), "sst_conv_pack_multi")
+        return self.out
+
+
+def packed_weights(cache: dict, key, weights, modes):
+    """cache: a dict living on the module.  Returns the list of packed tensors (freshly re-packed)."""
+    plan = cache.get(key)
+    if plan is None or not plan.matches(weights):
+        plan = PackPlan(weights, modes)
+        cache[key] = plan
+    return plan.run()
+
+
+_COUNTERS = {}
+
+
+def _next_counter(device):
+    """One zeroed 32-bit word for a last-arriver kernel.  Kernels leave their word zero again, so a ring is enough;
+    under graph capture every captured launch simply keeps its own word."""
+    st = _COUNTERS.get(device)
+    if st is None:
+        st = [torch.zeros(8192, device=device, dtype=torch.int32), 0]
+        _COUNTERS[device] = st
+    i = st[1]
+    st[1] = (i + 1) % 8192
+    return st[0].data_ptr() + 4 * i
+
+
+def bwd_reduce_finalize(g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
+                        gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False):
+    """bwd_reduce + bwd_finalize in one launch.  Returns (cA, cB, cC) in BN mode (mean given), else (None,)*3."""
+    C = y.shape[-1]
+    R = y.numel() // C
+    nblk = _abi.lib().sst_bwd_reduce_blocks(R, C)
+    partial = _f32(nblk, 3, C, like=y)
+    cA = cB = cC = None
+    if mean is not None:
+        cA, cB, cC = (_f32(C, like=y) for _ in range(3))
+    check(_abi.lib().sst_bwd_reduce_finalize(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const),
+                                             int(act), ptr(partial), R, C, _next_counter(y.device), float(n), ptr(mean), ptr(rstd),
+                                             ptr(gamma), ptr(dgamma), ptr(dbeta), ptr(cA), ptr(cB), ptr(cC), ptr(dslope),
+                                             int(accumulate), stream_ptr()), "sst_bwd_reduce_finalize")
+    return cA, cB, cC
+
+
+def flatten_bn_counters(module):
+    """Make every BatchNorm's num_batches_tracked a view of one int64 tensor so a train-mode forward bumps them
+    with a single add (33 launches -> 1 for the generator).  Idempotent; re-done if the buffers were moved."""
+    bns = [m for m in module.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    if not bns:
+        return None
+    flat = getattr(module, "_nbt_flat", None)
+    ok = flat is not None and flat.device == bns[0].num_batches_tracked.device and all(
+        bn.num_batches_tracked.data_ptr() == flat.data_ptr() + 8 * i for i, bn in enumerate(bns))
+    if not ok:
+        flat = torch.stack([bn.num_batches_tracked.detach().to(torch.int64) for bn in bns])
+        for i, bn in enumerate(bns):
+            bn._buffers["num_batches_tracked"] = flat[i]
+        module._nbt_flat = flat
+    return flat
