@@ -68,6 +68,18 @@ int sst_wgrad_c3(const float* big, const float* small, float* slab, float* dw, c
                  float in_slope_const, int in_act, int kind, int B, int H, int W, int C, int accumulate,
                  void* stream);
 
+/* forward of the same two convs with the folding on the K side (conv1: 3->C, also conv3's data-gradient with
+ * mode 1 weights) resp. the N side (conv3: C->3, stores NCHW + clamp like out_mode 2 of sst_conv_fwd). */
+int64_t sst_conv9_c3_packed_floats(int Cout_eff);
+int sst_conv9_c3_pack(const float* w, float* wp, int Cout, int Cin, int mode, void* stream);
+int sst_conv9_c3_fwd(const float* x, const float* wp, float* y, const float* bias, int B, int H, int W,
+                     int Cout, void* stream);
+int64_t sst_conv9_to3_packed_floats(int C);
+int sst_conv9_to3_pack(const float* w, float* wp, int C, void* stream);
+int sst_conv9_to3_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,
+                      const float* in_slope, float in_slope_const, int in_act, int B, int H, int W, int C,
+                      void* stream);
+
 /* data-gradient of a 3x3 / stride-2 / pad-1 conv (Discriminator.features model.py:35,42,49,56): the input-gradient
  * pixels are split into 4 parity classes, each a dense 1x1 / 1x2 / 2x1 / 2x2 correlation over dy. */
 int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin);

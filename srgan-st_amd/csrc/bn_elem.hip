@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
     if (s_last) {
       if (threadIdx.x == 0) acquire_after_ticket();
       __syncthreads();
-      bwd_finalize_body<NT, true>(partial, gridDim.x, C, fin, sm, sm + 3 * NT);
+      bwd_finalize_body<NT, false>(partial, gridDim.x, C, fin, sm, sm + 3 * NT);   // plain loads: the acquire above + barrier cover the CU's L1
       if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -190,3 +190,313 @@ SST_API int sst_wgrad_c3(const float* big, const float* small, float* slab, floa
   SST_LAUNCH_CHECK("c3_reduce_kernel");
   return SST_OK;
 }
+
+// =================================================================================================
+// conv9_c3_fwd: 9x9 convolution FROM a 3-channel NHWC tensor TO Cout channels (Generator.conv1 forward,
+// model.py:101; and the data-gradient of conv3, model.py:127, with transposed+rotated weights).
+//   GEMM: M = pixels, N = Cout, K = (ky, j) with j = 3*kx + ch3 in [0,27) padded to 32  ->  36 chunks of 8
+//   (the generic kernel spends 81 chunks on the same work because a tap only carries 3 of 8 k-lanes).
+// Workgroup = 4 rows x 32 pixels, one wave per row, one 32x32 accumulator per wave (no K split, no LDS
+// reduction).  The 3-channel input band (4+8 rows) sits in LDS; the A fragment is a sliding window over it.
+namespace {
+
+constexpr int F_TW = 32, F_TH = 4;
+constexpr int F_RS = (F_TW + 8) * 3 + 24;     // band row stride: window reads reach 3*31 + 31 = 124 < F_RS
+
+struct C3FwdArgs {
+  const float* x;      // [B,H,W,3]
+  const float* wp;     // packed: [(Cout+31)/32][9][4][64 lanes][4]
+  float* y;            // [B,H,W,Cout]
+  const float* bias;   // [Cout] or null
+  int B, H, W, Cout;
+};
+
+__global__ __launch_bounds__(CONV_NT) void conv9_c3_fwd_kernel(C3FwdArgs a) {
+  __shared__ float sS[(F_TH + 8) * F_RS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_x = (a.W + F_TW - 1) / F_TW, tiles_y = (a.H + F_TH - 1) / F_TH;
+  const int mt = blockIdx.x;
+  const int b = mt / (tiles_x * tiles_y), rt = mt - b * tiles_x * tiles_y;
+  const int y0 = (rt / tiles_x) * F_TH, x0 = (rt % tiles_x) * F_TW;
+  const int nf = blockIdx.y;
+  const float* wblk = a.wp + (size_t)nf * 36 * 256 + lane * 4;
+
+  // B fragments: 36 chunks, 3-deep ping-pong like the generic kernel (36 = 6 x 6: no tail)
+  int p_i = 0;
+  auto pf_load = [&]() {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wblk + (size_t)(p_i < 36 ? p_i : 35) * 256);
+    ++p_i;
+    return v;
+  };
+  f32x4 A0 = pf_load(), A1 = pf_load(), A2 = pf_load(), B0, B1, B2;
+
+  for (int i = tid; i < (F_TH + 8) * F_RS; i += CONV_NT) {
+    const int r = i / F_RS, o = i - r * F_RS;
+    float v = 0.f;
+    const int y = y0 - 4 + r;
+    if (o < (F_TW + 8) * 3 && (unsigned)y < (unsigned)a.H) {
+      const int px = o / 3, ch = o - px * 3, x = x0 - 4 + px;
+      if ((unsigned)x < (unsigned)a.W) v = a.x[(((size_t)b * a.H + y) * a.W + x) * 3 + ch];
+    }
+    sS[i] = v;
+  }
+  __syncthreads();
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // window of output pixel li for (ky, c4): band row (wave + ky), floats [3*li + 8*c4 + 4*lh, +4)
+  int a_off = wave * F_RS + 3 * li + 4 * lh, a_c4 = 0;
+  auto a_load = [&]() {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = sS[a_off + j];
+    const bool wrap = (a_c4 == 3);
+    a_off += wrap ? F_RS - 24 : 8;
+    a_c4 = wrap ? 0 : a_c4 + 1;
+    return v;
+  };
+#define SST_C3_CHUNK(BUSE, BLOAD)                                                                      \
+  {                                                                                                    \
+    const f32x4 av = a_load();                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], BUSE[j], acc, 0, 0, 0);                      \
+    BLOAD = pf_load();                                                                                 \
+  }
+  for (int c = 0; c < 36; c += 6) {
+    SST_C3_CHUNK(A0, B0)
+    SST_C3_CHUNK(A1, B1)
+    SST_C3_CHUNK(A2, B2)
+    SST_C3_CHUNK(B0, A0)
+    SST_C3_CHUNK(B1, A1)
+    SST_C3_CHUNK(B2, A2)
+  }
+#undef SST_C3_CHUNK
+  // ---- store: acc[r] = out[pixel (r&3)+8(r>>2)+4lh][cout li]
+  const int oy = y0 + wave, co = nf * 32 + li;
+  if (oy < a.H && co < a.Cout) {
+    const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ox < a.W) a.y[(((size_t)b * a.H + oy) * a.W + ox) * a.Cout + co] = acc[r] + bv;
+    }
+  }
+}
+
+// w [Cout][Cin][9][9] -> packed for conv9_c3_fwd.  mode 0: Cin must be 3 (conv1 forward).
+// mode 1: Cout must be 3 (data-gradient of conv3): outputs = Cin, inputs = Cout, taps rotated 180 degrees.
+__global__ void pack_c3_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int mode) {
+  const int O = mode ? Cin : Cout;
+  const int total = ((O + 31) / 32) * 36 * 256;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int jj = idx & 3, l = (idx >> 2) & 63;
+    const int chunk = (idx >> 8) % 36, of = (idx >> 8) / 36;
+    const int ky = chunk >> 2, c4 = chunk & 3;
+    const int o = of * 32 + (l & 31), j = c4 * 8 + (l >> 5) * 4 + jj;
+    float v = 0.f;
+    if (o < O && j < 27) {
+      const int kx = j / 3, ch = j - 3 * kx;
+      v = mode == 0 ? w[(((size_t)o * Cin + ch) * 9 + ky) * 9 + kx]
+                    : w[(((size_t)ch * Cin + o) * 9 + (8 - ky)) * 9 + (8 - kx)];
+    }
+    wp[idx] = v;
+  }
+}
+
+}  // namespace
+
+SST_API int64_t sst_conv9_c3_packed_floats(int Cout_eff) { return (int64_t)((Cout_eff + 31) / 32) * 36 * 256; }
+
+SST_API int sst_conv9_c3_pack(const float* w, float* wp, int Cout, int Cin, int mode, void* stream) {
+  SST_REQUIRE(w && wp && Cout > 0 && Cin > 0 && (mode == 0 ? Cin == 3 : Cout == 3), "sst_conv9_c3_pack: the 3-channel side is missing");
+  const int O = mode ? Cin : Cout;
+  const int total = ((O + 31) / 32) * 36 * 256;
+  pack_c3_fwd_kernel<<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(w, wp, Cout, Cin, mode);
+  SST_LAUNCH_CHECK("pack_c3_fwd_kernel");
+  return SST_OK;
+}
+
+// y [B,H,W,Cout] = conv9x9(x [B,H,W,3]) (+ bias), pad 4, stride 1
+SST_API int sst_conv9_c3_fwd(const float* x, const float* wp, float* y, const float* bias, int B, int H, int W, int Cout,
+                             void* stream) {
+  SST_REQUIRE(x && wp && y && B > 0 && H > 0 && W > 0 && Cout > 0, "sst_conv9_c3_fwd: bad argument");
+  C3FwdArgs a;
+  a.x = x; a.wp = wp; a.y = y; a.bias = bias; a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+  const int64_t mt = (int64_t)B * ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW);
+  SST_REQUIRE(mt < (1ll << 31), "sst_conv9_c3_fwd: too many tiles");
+  conv9_c3_fwd_kernel<<<dim3((unsigned)mt, (Cout + 31) / 32), CONV_NT, 0, sst_stream(stream)>>>(a);
+  SST_LAUNCH_CHECK("conv9_c3_fwd_kernel");
+  return SST_OK;
+}
+
+// =================================================================================================
+// conv9_to3_fwd: 9x9 convolution from C channels TO 3 channels (Generator.conv3 forward + clamp, model.py:127,148-150).
+//   Step 1 (MFMA): T[y][x'][q] = sum_{ky,ci} P[y+ky-4][x'][ci] * W[co][ci][ky][kx],  q = 3*kx + co  (27 of 32 columns)
+//   Step 2 (LDS) : out[y][x][co] = bias[co] + sum_kx T[y][x+kx-4][3*kx+co]
+// Workgroup = 512 threads = 8 rows x 24 output pixels (32-pixel M fragment incl. the +-4 halo), one wave per row;
+// the 16-row x 32-pixel x 64-channel input patch is staged once in LDS (139 KB) and reused by all 9 ky.
+namespace {
+
+constexpr int T3_TH = 8, T3_TW = 24, T3_NT = 512;
+constexpr int T3_PW = 32, T3_PH = T3_TH + 8;
+
+struct To3Args {
+  const float* x;        // [B,H,W,C]
+  const float* wp;       // packed [ncb][9][8][64 lanes][4] (+ PACK_PAD zeros)
+  float* y;              // [B,3,H,W]  clamp(out,0,1)
+  float* y_pre;          // [B,3,H,W]  out (saved for backward) or null
+  const float* bias;     // [3] or null
+  const float* in_slope; // device scalar or null
+  float in_slope_const;
+  int in_act;
+  int B, H, W, C;
+};
+
+__global__ __launch_bounds__(T3_NT) void conv9_to3_fwd_kernel(To3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [T3_PH][T3_PW][LDSC]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_x = (a.W + T3_TW - 1) / T3_TW, tiles_y = (a.H + T3_TH - 1) / T3_TH;
+  const int mt = blockIdx.x;
+  const int b = mt / (tiles_x * tiles_y), rt = mt - b * tiles_x * tiles_y;
+  const int y0 = (rt / tiles_x) * T3_TH, x0 = (rt % tiles_x) * T3_TW;
+  const int ncb = (a.C + CB - 1) / CB;
+  const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
+  const float* wzero = a.wp + (size_t)ncb * 9 * 8 * 256 + lane * 4;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int cb = 0; cb < ncb; ++cb) {
+    const int c0 = cb * CB;
+    const int nks = (min(CB, a.C - c0) + 7) >> 3;
+    const int nchunks = 9 * nks;
+    const float* wblk = a.wp + (size_t)cb * 9 * 8 * 256 + lane * 4;
+    int p_ks = 0, p_off = 0, p_i = 0;
+    auto pf_load = [&]() {
+      const float* src = p_i < nchunks ? wblk + p_off : wzero;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      const bool wrap = (p_ks + 1 == nks);
+      p_ks = wrap ? 0 : p_ks + 1;
+      p_off += wrap ? (9 - nks) * 256 : 256;
+      ++p_i;
+      return v;
+    };
+    f32x4 A0 = pf_load(), A1 = pf_load(), A2 = pf_load(), B0, B1, B2;
+    if (cb) __syncthreads();
+    {
+      const int c4 = (tid & 15) * 4, c = c0 + c4;
+      for (int p = tid >> 4; p < T3_PH * T3_PW; p += T3_NT / 16) {
+        const int py = p / T3_PW, px = p - py * T3_PW;
+        const int iy = y0 - 4 + py, ix = x0 - 4 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.C) {
+          v = *reinterpret_cast<const f32x4*>(a.x + (((size_t)b * a.H + iy) * a.W + ix) * a.C + c);
+          if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+          }
+        }
+        *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = v;
+      }
+    }
+    __syncthreads();
+    // A cursor: patch row (wave + ky), pixel li, channels ks*8 + 4*lh
+    int a_off = (wave * T3_PW + li) * LDSC + 4 * lh, a_ks = 0, a_i = 0;
+    auto a_load = [&]() {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[a_off]);
+      const bool live = a_i + 1 < nchunks;
+      const bool wrap = (a_ks + 1 == nks);
+      a_off += live ? (wrap ? T3_PW * LDSC - 8 * (nks - 1) : 8) : 0;
+      a_ks = wrap ? 0 : a_ks + 1;
+      ++a_i;
+      return v;
+    };
+#define SST_T3_CHUNK(BUSE, BLOAD)                                                                      \
+    {                                                                                                  \
+      const f32x4 av = a_load();                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], BUSE[j], acc, 0, 0, 0);                    \
+      BLOAD = pf_load();                                                                               \
+    }
+    for (int c = 0; c < nchunks; c += 6) {
+      SST_T3_CHUNK(A0, B0)
+      SST_T3_CHUNK(A1, B1)
+      SST_T3_CHUNK(A2, B2)
+      SST_T3_CHUNK(B0, A0)
+      SST_T3_CHUNK(B1, A1)
+      SST_T3_CHUNK(B2, A2)
+    }
+#undef SST_T3_CHUNK
+  }
+  // ---- T -> LDS (overlays the patch), then the horizontal fold
+  __syncthreads();
+  float* sT = lds;   // [T3_TH][32][33]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sT[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+  __syncthreads();
+  for (int i = tid; i < T3_TH * 3 * T3_TW; i += T3_NT) {
+    const int x = i % T3_TW, t = i / T3_TW, co = t % 3, r = t / 3;
+    const int oy = y0 + r, ox = x0 + x;
+    if (oy < a.H && ox < a.W) {
+      float s = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int kx = 0; kx < 9; ++kx) s += sT[(r * 32 + x + kx) * 33 + 3 * kx + co];
+      const size_t o = (((size_t)b * 3 + co) * a.H + oy) * a.W + ox;
+      if (a.y_pre) a.y_pre[o] = s;
+      a.y[o] = fminf(fmaxf(s, 0.f), 1.f);
+    }
+  }
+}
+
+// w [3][C][9][9] -> packed [ncb][ky][ks 0..7][lane][4]: B[k=(ky,ci)][n=3kx+co] (+ PACK_PAD zeros at the end)
+__global__ void pack_to3_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int64_t total) {
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int jj = idx & 3, l = (idx >> 2) & 63, ks = (idx >> 8) & 7;
+    const int64_t rest = idx >> 11;
+    const int ky = (int)(rest % 9), cb = (int)(rest / 9);
+    const int q = l & 31, ci = cb * 64 + ks * 8 + (l >> 5) * 4 + jj;
+    float v = 0.f;
+    if (cb < (C + 63) / 64 && q < 27 && ci < C) {
+      const int kx = q / 3, co = q - 3 * kx;
+      v = w[(((size_t)co * C + ci) * 9 + ky) * 9 + kx];
+    }
+    wp[idx] = v;
+  }
+}
+
+}  // namespace
+
+SST_API int64_t sst_conv9_to3_packed_floats(int C) { return (int64_t)((C + 63) / 64) * 9 * 8 * 256 + PACK_PAD; }
+
+SST_API int sst_conv9_to3_pack(const float* w, float* wp, int C, void* stream) {
+  SST_REQUIRE(w && wp && C > 0, "sst_conv9_to3_pack: bad argument");
+  const int64_t total = sst_conv9_to3_packed_floats(C);
+  pack_to3_kernel<<<(int)((total + 255) / 256), 256, 0, sst_stream(stream)>>>(w, wp, C, total);
+  SST_LAUNCH_CHECK("pack_to3_kernel");
+  return SST_OK;
+}
+
+// y [B,3,H,W] = clamp(conv9x9(act(x [B,H,W,C])) + bias, 0, 1);  y_pre = pre-clamp copy (or null)
+SST_API int sst_conv9_to3_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias, const float* in_slope,
+                              float in_slope_const, int in_act, int B, int H, int W, int C, void* stream) {
+  SST_REQUIRE(x && wp && y && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "sst_conv9_to3_fwd: bad argument");
+  To3Args a;
+  a.x = x; a.wp = wp; a.y = y; a.y_pre = y_pre; a.bias = bias; a.in_slope = in_slope; a.in_slope_const = in_slope_const;
+  a.in_act = in_act; a.B = B; a.H = H; a.W = W; a.C = C;
+  const int64_t mt = (int64_t)B * ((H + T3_TH - 1) / T3_TH) * ((W + T3_TW - 1) / T3_TW);
+  SST_REQUIRE(mt < (1ll << 31), "sst_conv9_to3_fwd: too many tiles");
+  const size_t smem = (size_t)T3_PH * T3_PW * LDSC * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_to3_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+    attr_set = true;
+  }
+  conv9_to3_fwd_kernel<<<(unsigned)mt, T3_NT, smem, sst_stream(stream)>>>(a);
+  SST_LAUNCH_CHECK("conv9_to3_fwd_kernel");
+  return SST_OK;
+}

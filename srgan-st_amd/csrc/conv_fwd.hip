@@ -474,8 +474,10 @@ SST_API int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre
   SST_REQUIRE(mt < (1ll << 31), "sst_conv_fwd: too many tiles");
   dim3 grid((unsigned)mt, (Cout + 31) / 32);
   hipStream_t st = sst_stream(stream);
+  const size_t extra_lds = (size_t)(dbg_bits >> 4) * 1024;   // dev knob: pad LDS to cap workgroups per CU
+  a.dbg = dbg_bits & 15;
   if (ksize == 3 && stride == 1)
-    conv_fwd_kernel<3, 1><<<grid, CONV_NT, 0, st>>>(a);
+    conv_fwd_kernel<3, 1><<<grid, CONV_NT, extra_lds, st>>>(a);
   else if (ksize == 3)
     conv_fwd_kernel<3, 2><<<grid, CONV_NT, 0, st>>>(a);
   else

@@ -53,6 +53,12 @@ SIGNATURES = {
     "sst_wgrad_c3_supported": (c_int, [c_int, c_int]),
     "sst_wgrad_c3_slab_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "sst_wgrad_c3": (c_int, [P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_conv9_c3_packed_floats": (c_int64, [c_int]),
+    "sst_conv9_c3_pack": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "sst_conv9_c3_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "sst_conv9_to3_packed_floats": (c_int64, [c_int]),
+    "sst_conv9_to3_pack": (c_int, [P, P, c_int, P]),
+    "sst_conv9_to3_fwd": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_s2_dgrad_packed_floats": (c_int64, [c_int, c_int]),
     "sst_conv_s2_dgrad_pack": (c_int, [P, P, c_int, c_int, P]),
     "sst_conv_s2_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

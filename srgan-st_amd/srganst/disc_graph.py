@@ -71,7 +71,9 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
     dh1 = ops.head_bwd(h1, p["classifier.2.weight"], dout.contiguous(), LRELU,
                        dw=G("classifier.2.weight") if wg else None, db=G("classifier.2.bias") if wg else None)
     if wg:
-        ops.linear_wgrad(dh1, flat, G("classifier.0.weight"), G("classifier.0.bias"))
+        dw0, db0 = G("classifier.0.weight"), G("classifier.0.bias")
+        with ops.SideStream(dh1, flat, dw0, db0):
+            ops.linear_wgrad(dh1, flat, dw0, db0)
     last = sv["layers"][-1]
     B, H, W, C = last["y"].shape
     g = ops.linear_dgrad(dh1, p["classifier.0.weight"], nhwc=(C, H * W)).view(B, H, W, C)   # d LReLU(BN(y_last)) in NHWC
@@ -95,8 +97,10 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
                 ops.bwd_reduce_finalize(g, y, n, slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"))
             dy = ops.bwd_apply(g, y, slope_const=LRELU, act=1)
         if wg:
-            ops.conv_wgrad(r["x"], dy, G(f"features.{ci}.weight"), 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
-                           in_slope_const=LRELU, in_act=r["x_act"])
+            dwc = G(f"features.{ci}.weight")
+            with ops.SideStream(r["x"], dy, dwc):
+                ops.conv_wgrad(r["x"], dy, dwc, 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
+                               in_slope_const=LRELU, in_act=r["x_act"])
         if li == 0 and not need_dx:
             break
         xin = r["x"]
@@ -106,6 +110,7 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
             g = ops.conv_s2_dgrad(dy, ops.pack_conv_s2_dgrad(w), xin.shape[1], xin.shape[2], w.shape[1])
         if li == 0:
             dx = ops.transpose(g, to_nchw=True)
+    ops.join_side()
     return grads, dx
 
 

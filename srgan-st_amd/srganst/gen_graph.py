@@ -30,20 +30,28 @@ def _bn_buffers(bn, training):
     return (bn.running_mean, bn.running_var) if training else (None, None)
 
 
-def _conv_names(module):
-    names = ["conv1.0.weight"]
+def _fast9(module, p):
+    """The 9x9 convs take the (kx, 3ch)-folded kernels when their small side has exactly 3 channels (the reference's
+    RGB configuration) and C is a multiple of 4 that the wgrad kernel supports."""
+    C = p["conv1.0.weight"].shape[0]
+    return p["conv1.0.weight"].shape[1] == 3 and p["conv3.weight"].shape[0] == 3 and ops.wgrad_c3_supported(C)
+
+
+def _conv_names(module, fast9):
+    names = [] if fast9 else ["conv1.0.weight"]
     for i in range(len(module.trunk)):
         names += [f"trunk.{i}.rcb.0.weight", f"trunk.{i}.rcb.3.weight"]
     names.append("conv2.0.weight")
     names += [f"upsampling.{j}.upsample_block.0.weight" for j in range(len(module.upsampling))]
-    names.append("conv3.weight")
+    if not fast9:
+        names.append("conv3.weight")
     return names
 
 
 def _packs(module, p, mode):
     """name -> packed weight (mode 0 forward / mode 1 data-gradient); one multi-tensor launch."""
     cache = module.__dict__.setdefault("_hip_cache", {})
-    names = _conv_names(module)
+    names = _conv_names(module, _fast9(module, p))
     ws = [p[n] for n in names]
     return dict(zip(names, ops.packed_weights(cache, ("pack", mode), ws, [mode] * len(ws))))
 
@@ -57,7 +65,11 @@ def forward(module, x, params, need_grad):
     if training:
         ops.flatten_bn_counters(module).add_(1)
     x3 = ops.transpose(x.contiguous(), to_nchw=False)                                  # [B,h,w,3]
-    z1, _, _, _ = ops.conv_fwd(x3, wp["conv1.0.weight"], C, 9, 1, bias=p["conv1.0.bias"])
+    fast9 = _fast9(module, p)
+    if fast9:
+        z1 = ops.conv9_c3_fwd(x3, p["conv1.0.weight"], 0, bias=p["conv1.0.bias"])
+    else:
+        z1, _, _, _ = ops.conv_fwd(x3, wp["conv1.0.weight"], C, 9, 1, bias=p["conv1.0.bias"])
     a1 = p["conv1.1.weight"]
     sv["x3"], sv["z1"] = x3, z1
 
@@ -98,9 +110,13 @@ def forward(module, x, params, need_grad):
         u, slope = us, p[pre + ".2.weight"]
     sv["ups"] = ups
     cout = p["conv3.weight"].shape[0]
-    sr, sr_pre, _, _ = ops.conv_fwd(u, wp["conv3.weight"], cout, 9, 1, bias=p["conv3.bias"], in_slope=slope,
-                                    in_act=ACT_SLOPE if slope is not None else 0, out_mode=OUT_NCHW_CLAMP,
-                                    want_pre=need_grad)
+    if fast9:
+        sr, sr_pre = ops.conv9_to3_fwd(u, p["conv3.weight"], bias=p["conv3.bias"], in_slope=slope,
+                                       in_act=ACT_SLOPE if slope is not None else 0, want_pre=need_grad)
+    else:
+        sr, sr_pre, _, _ = ops.conv_fwd(u, wp["conv3.weight"], cout, 9, 1, bias=p["conv3.bias"], in_slope=slope,
+                                        in_act=ACT_SLOPE if slope is not None else 0, out_mode=OUT_NCHW_CLAMP,
+                                        want_pre=need_grad)
     sv["last"] = (u, slope, sr_pre)
     return sr, sv
 
@@ -119,13 +135,16 @@ def backward(module, params, sv, dsr, need_dx=False):
     # ---- conv3 + clamp
     u, slope, sr_pre = sv["last"]
     g3 = ops.clamp_bwd(dsr.contiguous(), sr_pre, dbias=grads["conv3.bias"])
-    cout3 = p["conv3.weight"].shape[0]
-    fast9 = cout3 == 3 and sv["x3"].shape[-1] == 3 and ops.wgrad_c3_supported(C)
+    fast9 = _fast9(module, p)
+    with ops.SideStream(u, g3, grads["conv3.weight"]):
+        if fast9:
+            ops.wgrad_c3(u, g3, grads["conv3.weight"], 0, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
+        else:
+            ops.conv_wgrad(u, g3, grads["conv3.weight"], 9, 1, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
     if fast9:
-        ops.wgrad_c3(u, g3, grads["conv3.weight"], 0, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
+        g = ops.conv9_c3_fwd(g3, p["conv3.weight"], 1)              # d PReLU(u)
     else:
-        ops.conv_wgrad(u, g3, grads["conv3.weight"], 9, 1, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
-    g = ops.conv_fwd(g3, wd["conv3.weight"], C, 9, 1)[0]          # d PReLU(u)
+        g = ops.conv_fwd(g3, wd["conv3.weight"], C, 9, 1)[0]
     # ---- up-sampling blocks, last to first
     for j in reversed(range(len(sv["ups"]))):
         pre = f"upsampling.{j}.upsample_block"
@@ -134,8 +153,9 @@ def backward(module, params, sv, dsr, need_dx=False):
         ops.bwd_reduce_finalize(g, us, rows(us), slope=sl, act=1, dslope=grads[pre + ".2.weight"])
         du = ops.bwd_apply(g, us, slope=sl, act=1, unshuffle=True)                  # [B,h,w,4C] pre-shuffle grad
         ops.bwd_reduce_finalize(du, du, rows(du), dbeta=grads[pre + ".0.bias"])
-        ops.conv_wgrad(u_in, du, grads[pre + ".0.weight"], 3, 1, in_slope=slope_in,
-                       in_act=ACT_SLOPE if slope_in is not None else 0)
+        with ops.SideStream(u_in, du, grads[pre + ".0.weight"]):
+            ops.conv_wgrad(u_in, du, grads[pre + ".0.weight"], 3, 1, in_slope=slope_in,
+                           in_act=ACT_SLOPE if slope_in is not None else 0)
         g = ops.conv_fwd(du, wd[pre + ".0.weight"], C, 3, 1)[0]    # d (input of the up-conv)
     # ---- u = BN(conv2(h_last)) + PReLU(z1)
     y3, m3, r3, s3, t3 = sv["conv2"]
@@ -143,8 +163,9 @@ def backward(module, params, sv, dsr, need_dx=False):
     cA, cB, cC = ops.bwd_reduce_finalize(g, y3, n, scale=s3, shift=t3, mean=m3, rstd=r3, gamma=p["conv2.1.weight"],
                                          dgamma=grads["conv2.1.weight"], dbeta=grads["conv2.1.bias"])
     dy3 = ops.bwd_apply(g, y3, cA=cA, cB=cB, cC=cC)
-    ops.conv_wgrad(sv["h_last"], dy3, grads["conv2.0.weight"], 3, 1,
-                   in_slope=a1 if not sv["blocks"] else None, in_act=ACT_SLOPE if not sv["blocks"] else 0)
+    with ops.SideStream(sv["h_last"], dy3, grads["conv2.0.weight"]):
+        ops.conv_wgrad(sv["h_last"], dy3, grads["conv2.0.weight"], 3, 1,
+                       in_slope=a1 if not sv["blocks"] else None, in_act=ACT_SLOPE if not sv["blocks"] else 0)
     dskip = g
     dh = ops.conv_fwd(dy3, wd["conv2.0.weight"], C, 3, 1)[0]
     # ---- residual blocks, last to first
@@ -156,26 +177,31 @@ def backward(module, params, sv, dsr, need_dx=False):
         cA, cB, cC = ops.bwd_reduce_finalize(dh, y2, n, scale=s2, shift=t2, mean=m2, rstd=r2, gamma=p[pre + ".4.weight"],
                                              dgamma=grads[pre + ".4.weight"], dbeta=grads[pre + ".4.bias"])
         dy2 = ops.bwd_apply(dh, y2, cA=cA, cB=cB, cC=cC)
-        ops.conv_wgrad(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
+        with ops.SideStream(y1, dy2, grads[pre + ".3.weight"]):
+            ops.conv_wgrad(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
         dp1 = ops.conv_fwd(dy2, wd[pre + ".3.weight"], C, 3, 1)[0]
         cA, cB, cC = ops.bwd_reduce_finalize(dp1, y1, n, scale=s1, shift=t1, slope=sl, act=1, mean=m1, rstd=r1,
                                              gamma=p[pre + ".1.weight"], dgamma=grads[pre + ".1.weight"],
                                              dbeta=grads[pre + ".1.bias"], dslope=grads[pre + ".2.weight"])
         dy1 = ops.bwd_apply(dp1, y1, scale=s1, shift=t1, slope=sl, act=1, cA=cA, cB=cB, cC=cC)
-        ops.conv_wgrad(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None,
-                       in_act=ACT_SLOPE if first else 0)
+        with ops.SideStream(h, dy1, grads[pre + ".0.weight"]):
+            ops.conv_wgrad(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None,
+                           in_act=ACT_SLOPE if first else 0)
         dh = ops.conv_fwd(dy1, wd[pre + ".0.weight"], C, 3, 1, residual=dh)[0]
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
     ops.bwd_reduce_finalize(dh, z1, n, g2=dskip, slope=a1, act=1, dbeta=grads["conv1.0.bias"], dslope=grads["conv1.1.weight"])
     dz1 = ops.bwd_apply(dh, z1, g2=dskip, slope=a1, act=1)
-    if fast9:
-        ops.wgrad_c3(dz1, sv["x3"], grads["conv1.0.weight"], 1)
-    else:
-        ops.conv_wgrad(sv["x3"], dz1, grads["conv1.0.weight"], 9, 1)
+    with ops.SideStream(dz1, sv["x3"], grads["conv1.0.weight"]):
+        if fast9:
+            ops.wgrad_c3(dz1, sv["x3"], grads["conv1.0.weight"], 1)
+        else:
+            ops.conv_wgrad(sv["x3"], dz1, grads["conv1.0.weight"], 9, 1)
+    ops.join_side()
     dx = None
     if need_dx:
-        dx3 = ops.conv_fwd(dz1, wd["conv1.0.weight"], sv["x3"].shape[-1], 9, 1)[0]
+        wd1 = ops.pack_conv(p["conv1.0.weight"], 1) if fast9 else wd["conv1.0.weight"]
+        dx3 = ops.conv_fwd(dz1, wd1, sv["x3"].shape[-1], 9, 1)[0]
         dx = ops.transpose(dx3, to_nchw=True)
     return [grads[n] for n in module._names], dx
 

@@ -395,3 +395,76 @@ def flatten_bn_counters(module):
             bn._buffers["num_batches_tracked"] = flat[i]
         module._nbt_flat = flat
     return flat
+
+
+# ------------------------------------------------------------------------------------------------
+# Second HIP stream for work that is off the critical chain of backward (weight gradients): under hipGraph
+# capture the fork/join below becomes two parallel branches of the graph.
+OVERLAP = True
+_SIDE = {}
+
+
+class SideStream:
+    """with SideStream(tensors...):  the body runs on the side stream after everything issued so far on the
+    current stream; `tensors` (inputs/outputs touched by the body) are recorded for the caching allocator."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        if not OVERLAP:
+            return self
+        main = torch.cuda.current_stream()
+        side = _SIDE.get(main.device)
+        if side is None:
+            side = torch.cuda.Stream(device=main.device)
+            _SIDE[main.device] = side
+        side.wait_stream(main)
+        for t in self.tensors:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if OVERLAP:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_side():
+    """The current stream waits for the side stream (call once before the gradients are consumed)."""
+    if OVERLAP:
+        main = torch.cuda.current_stream()
+        side = _SIDE.get(main.device)
+        if side is not None:
+            main.wait_stream(side)
+
+
+def conv9_c3_fwd(x3, w, mode, bias=None):
+    """9x9 conv from a 3-channel NHWC tensor.  mode 0: w [Cout,3,9,9] (conv1 forward).  mode 1: w [3,C,9,9] and the
+    result is the data-gradient of that conv (C output channels)."""
+    B, H, W, _ = x3.shape
+    cout = w.shape[1] if mode else w.shape[0]
+    wp = _f32(_abi.lib().sst_conv9_c3_packed_floats(cout), like=w)
+    check(_abi.lib().sst_conv9_c3_pack(ptr(w), ptr(wp), w.shape[0], w.shape[1], mode, stream_ptr()), "sst_conv9_c3_pack")
+    y = _f32(B, H, W, cout, like=x3)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv9_c3_fwd(ptr(x3), ptr(wp), ptr(y), ptr(bias), B, H, W, cout, stream_ptr()), "sst_conv9_c3_fwd")
+    _prof_end(e0, "conv9_c3_fwd_kernel", 2.0 * B * H * W * cout * 3 * 81)
+    return y
+
+
+def conv9_to3_fwd(x, w, bias=None, in_slope=None, in_slope_const=0.0, in_act=ACT_NONE, want_pre=False):
+    """x [B,H,W,C] NHWC -> (clamp(conv9x9(act(x)) + bias, 0, 1) as NCHW [B,3,H,W], pre-clamp copy or None)."""
+    B, H, W, C = x.shape
+    assert tuple(w.shape) == (3, C, 9, 9)
+    wp = _f32(_abi.lib().sst_conv9_to3_packed_floats(C), like=w)
+    check(_abi.lib().sst_conv9_to3_pack(ptr(w), ptr(wp), C, stream_ptr()), "sst_conv9_to3_pack")
+    y = _f32(B, 3, H, W, like=x)
+    y_pre = torch.empty_like(y) if want_pre else None
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv9_to3_fwd(ptr(x), ptr(wp), ptr(y), ptr(y_pre), ptr(bias), ptr(in_slope), float(in_slope_const),
+                                       int(in_act), B, H, W, C, stream_ptr()), "sst_conv9_to3_fwd")
+    _prof_end(e0, "conv9_to3_fwd_kernel", 2.0 * B * H * W * C * 3 * 81)
+    return y, y_pre

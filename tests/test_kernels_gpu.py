@@ -223,3 +223,30 @@ def test_wgrad_c3_both_kinds(ops, case):
     dw1 = torch.zeros(C, 3, 9, 9).cuda()
     ops.wgrad_c3(nhwc(dz).cuda(), nhwc(x3).cuda(), dw1, 1)
     assert rel_err(dw1.cpu(), w1.grad) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64), (1, 13, 37, 8), (1, 96, 96, 64), (2, 9, 5, 16)])
+def test_conv9_folded_forward_kernels(ops, case):
+    """conv1-type (3->C), conv3 data-gradient (mode 1) and conv3 forward (C->3, NCHW + clamp) with the (kx,3ch) folding."""
+    B, H, W, C = case
+    g = torch.Generator().manual_seed(41)
+    x3 = torch.randn(B, 3, H, W, generator=g)
+    w1 = torch.randn(C, 3, 9, 9, generator=g) / 15.6
+    b1 = torch.randn(C, generator=g)
+    ref = F.conv2d(x3.double(), w1.double(), b1.double(), 1, 4)
+    y = ops.conv9_c3_fwd(nhwc(x3).cuda(), w1.cuda(), 0, bias=b1.cuda())
+    assert rel_err(nchw(y.cpu()), ref) < TOL
+    # conv3 forward + its data-gradient
+    u = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w3 = torch.randn(3, C, 9, 9, generator=g) / (C * 81) ** 0.5
+    b3 = torch.rand(3, generator=g)
+    pre = F.conv2d(F.prelu(u, torch.tensor([0.25], dtype=torch.float64)), w3.double(), b3.double(), 1, 4)
+    sr, sr_pre = ops.conv9_to3_fwd(nhwc(u.detach().float()).cuda(), w3.cuda(), bias=b3.cuda(), in_slope=torch.tensor([0.25]).cuda(),
+                                   in_act=ops.ACT_SLOPE, want_pre=True)
+    assert rel_err(sr_pre.cpu(), pre.detach()) < TOL
+    assert torch.equal(sr.cpu(), sr_pre.cpu().clamp(0, 1))
+    p = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(B, 3, H, W, generator=g)
+    F.conv2d(p, w3.double(), None, 1, 4).backward(dy.double())
+    dp = ops.conv9_c3_fwd(nhwc(dy).cuda(), w3.cuda(), 1)
+    assert rel_err(nchw(dp.cpu()), p.grad) < TOL

@@ -34,5 +34,8 @@ for (B, H, W, Cin, Cout, k, s) in shapes:
     for name, dbg in [("full", 0), ("no-staging", 1), ("no-kloop", 2), ("no-epilogue", 4), ("staging only", 6), ("kloop only", 5), ("epilogue only", 3), ("empty", 7)]:
         t = timeit(lambda: ops.conv_fwd(x, wp, Cout, k, s, out_mode=dbg << 8))
         print(f"   {name:14s} {t:8.1f} us   {flops/t/1e6:7.1f} TFLOP/s-equivalent")
+    for kb in (0, 24, 40, 60, 100):
+        t = timeit(lambda: ops.conv_fwd(x, wp, Cout, k, s, out_mode=(kb << 4) << 8))
+        print(f"   full, +{kb:3d} KB LDS pad   {t:8.1f} us   {flops/t/1e6:7.1f} TFLOP/s")
     t = timeit(lambda: ops.conv_fwd(x, wp, Cout, k, s, in_scale=sc, in_shift=sh, in_slope_const=0.2, in_act=1, want_stats=True))
     print(f"   {'full+bn+stats':14s} {t:8.1f} us   {flops/t/1e6:7.1f} TFLOP/s")
