@@ -33,7 +33,7 @@ struct WgC3Args {
 
 __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
   const int li = lane & 31, lh = lane >> 5;
   const int nfrag = (a.C + 31) >> 5;
   const int CL = nfrag * 32 + 4;                 // LDS row stride of the big operand
@@ -213,7 +213,7 @@ struct C3FwdArgs {
 
 __global__ __launch_bounds__(CONV_NT) void conv9_c3_fwd_kernel(C3FwdArgs a) {
   __shared__ float sS[(F_TH + 8) * F_RS];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
   const int li = lane & 31, lh = lane >> 5;
   const int tiles_x = (a.W + F_TW - 1) / F_TW, tiles_y = (a.H + F_TH - 1) / F_TH;
   const int mt = blockIdx.x;
@@ -356,7 +356,7 @@ struct To3Args {
 
 __global__ __launch_bounds__(T3_NT) void conv9_to3_fwd_kernel(To3Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [T3_PH][T3_PW][LDSC]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
   const int li = lane & 31, lh = lane >> 5;
   const int tiles_x = (a.W + T3_TW - 1) / T3_TW, tiles_y = (a.H + T3_TH - 1) / T3_TH;
   const int mt = blockIdx.x;

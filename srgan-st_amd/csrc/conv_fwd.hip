@@ -63,7 +63,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   __shared__ float sstat[4][2][32];
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
   const int tiles_x = (a.Wo + TWO - 1) / TWO, tiles_y = (a.Ho + THO - 1) / THO;
   const int mt = blockIdx.x;
   const int b = mt / (tiles_x * tiles_y), rt = mt - b * tiles_x * tiles_y;

@@ -32,7 +32,7 @@ struct WgradArgs {
 __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[SUB * WLD];
   __shared__ __attribute__((aligned(16))) float sD[SUB * WLD];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
   const int li = lane & 31, lh = lane >> 5;
   const int tap = blockIdx.y, ky = tap / a.KS, kx = tap - ky * a.KS;
   const int nci = (a.Cin + 63) / 64;

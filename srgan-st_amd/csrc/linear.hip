@@ -19,7 +19,7 @@ constexpr int MAXM = 64;   // batch rows supported (4 MFMA row tiles)
 __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ slab, int M, int N, int K, int kslice) {
   __shared__ float red[4][MAXM][17];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lj = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.x * 16;
   const int kb = blockIdx.y * kslice, ke = min(K, kb + kslice);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT) void linear_reduce_kernel(const float* __restri
 __global__ __launch_bounds__(NT) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                           float* __restrict__ dx, int M, int N, int K, int C, int HW) {
   __shared__ float red[4][16][65];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lj = lane & 15, lq = lane >> 4;
   const int k0 = blockIdx.x * 64;
   const int nper = ((N + 3) / 4 + 3) / 4 * 4;
