@@ -107,6 +107,16 @@ int sst_bwd_reduce_finalize(const float* g, const float* g2, const float* y, con
                             float* partial, int64_t R, int C, unsigned* counter, float n, const float* mean,
                             const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
                             float* cB, float* cC, float* dslope, int accumulate, void* stream);
+/* few-workgroup reduce + apply with the finalize folded into every workgroup's prologue (no hand-off at all) */
+int sst_bwd_reduce_blocks_small(int64_t R, int C);
+int sst_bwd_reduce_small(const float* g, const float* g2, const float* y, const float* scale,
+                         const float* shift, const float* slope, float slope_const, int act, float* partial,
+                         int64_t R, int C, void* stream);
+int sst_bwd_apply_fused(const float* g, const float* g2, const float* y, const float* scale,
+                        const float* shift, const float* slope, float slope_const, int act,
+                        const float* partial, int nblk, float n, const float* mean, const float* rstd,
+                        const float* gamma, float* dgamma, float* dbeta, float* dslope, int accumulate,
+                        float* dy, int64_t R, int C, int unshuffle_H, int unshuffle_W, void* stream);
 int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean,
                      const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
                      float* cB, float* cC, float* dslope, int accumulate, void* stream);

@@ -105,7 +105,8 @@ struct FinArgs {
 
 template <int FT, bool AGENT_LOADS>
 __device__ __forceinline__ void bwd_finalize_body(const float* __restrict__ partial, int nblk, int C, const FinArgs& f,
-                                                  float* sm /* [3][FT] */, float* red /* [FT/64] */) {
+                                                  float* sm /* [3][FT] */, float* red /* [FT/64] */,
+                                                  bool write_grads = true) {
   float al = 0.f;
   const int L = C >= FT ? 1 : FT / C;
   for (int cbase = 0; cbase < C; cbase += FT / L) {
@@ -142,24 +143,26 @@ __device__ __forceinline__ void bwd_finalize_body(const float* __restrict__ part
         const float mu = f.mean[c], rs = f.rstd[c], ga = f.gamma[c];
         const float sgh = rs * (s1 - mu * s0);   // sum gz * yhat
         const float m1 = s0 / f.n, m2 = sgh / f.n;
-        if (f.accumulate) {
-          f.dgamma[c] += sgh;
-          f.dbeta[c] += s0;
-        } else {
-          f.dgamma[c] = sgh;
-          f.dbeta[c] = s0;
+        if (write_grads) {
+          if (f.accumulate) {
+            f.dgamma[c] += sgh;
+            f.dbeta[c] += s0;
+          } else {
+            f.dgamma[c] = sgh;
+            f.dbeta[c] = s0;
+          }
         }
         const float a = ga * rs;
         f.cA[c] = a;
         f.cB[c] = -a * rs * m2;
         f.cC[c] = -a * m1 + a * rs * mu * m2;
-      } else if (f.dbeta) {
+      } else if (f.dbeta && write_grads) {
         if (f.accumulate) f.dbeta[c] += s0; else f.dbeta[c] = s0;
       }
     }
   }
   al = block_sum<FT>(al, red);
-  if (f.dslope && threadIdx.x == 0) {
+  if (f.dslope && write_grads && threadIdx.x == 0) {
     if (f.accumulate) f.dslope[0] += al; else f.dslope[0] = al;
   }
 }
@@ -289,6 +292,56 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
   }
 }
 
+// bwd_apply with the finalize folded in: each workgroup reduces the (few) per-workgroup partials of bwd_reduce
+// into LDS coefficients itself - no separate finalize launch, no inter-workgroup hand-off.  Workgroup 0 also
+// writes the parameter gradients (dgamma/dbeta/dslope).  C <= 512.
+constexpr int AF_MAXC = 512;
+__global__ __launch_bounds__(NT) void bwd_apply_fused_kernel(const float* __restrict__ g, const float* __restrict__ g2,
+                                                             const float* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ slope_p,
+                                                             float slope_c, int act, const float* __restrict__ partial,
+                                                             int nblk, FinArgs fin, float* __restrict__ dy, int64_t R, int C,
+                                                             int uH, int uW) {
+  __shared__ float sm[3 * NT + NT / 64];
+  __shared__ float sco[3 * AF_MAXC];
+  const bool bn = fin.mean != nullptr;
+  FinArgs f = fin;
+  f.cA = sco; f.cB = sco + AF_MAXC; f.cC = sco + 2 * AF_MAXC;
+  if (bn || blockIdx.x == 0) bwd_finalize_body<NT, false>(partial, nblk, C, f, sm, sm + 3 * NT, blockIdx.x == 0);
+  __syncthreads();
+  const int c4n = C >> 2;
+  const int64_t total = R * c4n;
+  const float slope = slope_p ? slope_p[0] : slope_c;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int c = (int)(i % c4n) * 4;
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    if (g2) gv += reinterpret_cast<const f32x4*>(g2)[i];
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gz = gv[j];
+      if (act) {
+        const float z = scale ? fmaf(yv[j], scale[c + j], shift[c + j]) : yv[j];
+        gz = z > 0.f ? gz : gz * slope;
+      }
+      o[j] = bn ? fmaf(sco[c + j], gz, fmaf(sco[AF_MAXC + c + j], yv[j], sco[2 * AF_MAXC + c + j])) : gz;
+    }
+    if (uW == 0) {
+      reinterpret_cast<f32x4*>(dy)[i] = o;
+    } else {
+      const int64_t r = i / c4n;
+      const int X = (int)(r % uW);
+      const int64_t t = r / uW;
+      const int Y = (int)(t % uH);
+      const int64_t b = t / uH;
+      float* d = dy + (((b * (uH >> 1) + (Y >> 1)) * (uW >> 1) + (X >> 1)) * (int64_t)(4 * C)) + 2 * (Y & 1) + (X & 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[4 * (c + j)] = o[j];
+    }
+  }
+}
+
 // out[i] = a[i] + b[i]
 __global__ __launch_bounds__(NT) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ out, int64_t n4) {
@@ -342,6 +395,12 @@ SST_API int sst_bn_residual(const float* y, const float* scale, const float* shi
   return SST_OK;
 }
 
+SST_API int sst_bwd_reduce_blocks_small(int64_t R, int C) {
+  int64_t nb = (R + 255) / 256;
+  if (nb > 32) nb = 32;
+  return (int)(nb < 1 ? 1 : nb);
+}
+
 SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
   // few, fat blocks: the tensors are L2-resident and the finalize kernel walks the partials
   int64_t nb = (R + 127) / 128;
@@ -351,11 +410,11 @@ SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
 
 static int launch_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
                              const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
-                             unsigned* counter, const FinArgs& fin, void* stream) {
+                             unsigned* counter, const FinArgs& fin, void* stream, int nblk_override = 0) {
   SST_REQUIRE(g && y && partial && R > 0 && C >= 4 && (C & 3) == 0 && C <= 1024, "sst_bwd_reduce: bad argument (C=%d)", C);
   SST_REQUIRE(NT % (C / 4) == 0 || C / 4 > NT, "sst_bwd_reduce: C/4 must divide %d", NT);
   SST_REQUIRE(C / 4 <= NT, "sst_bwd_reduce: C too large");
-  const int nblk = sst_bwd_reduce_blocks(R, C);
+  const int nblk = nblk_override ? nblk_override : sst_bwd_reduce_blocks(R, C);
   const int rpb = (int)((R + nblk - 1) / nblk);
   const int rowlanes = NT / (C / 4);
   size_t smem = (size_t)rowlanes * 3 * C * sizeof(float);
@@ -385,6 +444,36 @@ SST_API int sst_bwd_reduce_finalize(const float* g, const float* g2, const float
   SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_reduce_finalize: BN mode needs all BN pointers");
   FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
   return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, counter, fin, stream);
+}
+
+// bwd_reduce with few workgroups (sst_bwd_reduce_blocks_small) + bwd_apply with the finalize folded in.
+SST_API int sst_bwd_reduce_small(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                                 const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
+                                 void* stream) {
+  FinArgs fin = {};
+  return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, nullptr, fin, stream,
+                           sst_bwd_reduce_blocks_small(R, C));
+}
+
+SST_API int sst_bwd_apply_fused(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                                const float* slope, float slope_const, int act, const float* partial, int nblk, float n,
+                                const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta,
+                                float* dslope, int accumulate, float* dy, int64_t R, int C, int unshuffle_H, int unshuffle_W,
+                                void* stream) {
+  SST_REQUIRE(g && y && dy && partial && nblk > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= AF_MAXC,
+              "sst_bwd_apply_fused: bad argument (C=%d)", C);
+  SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta), "sst_bwd_apply_fused: BN mode needs rstd/gamma/dgamma/dbeta");
+  SST_REQUIRE(unshuffle_W == 0 || ((unshuffle_H & 1) == 0 && (unshuffle_W & 1) == 0 &&
+                                   R % ((int64_t)unshuffle_H * unshuffle_W) == 0),
+              "sst_bwd_apply_fused: bad unshuffle geometry");
+  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, nullptr, nullptr, nullptr, dslope, n, accumulate};
+  int64_t blocks = (R * (C / 4) + 4 * NT - 1) / (4 * NT);     // ~4 float4 per thread: amortises the coefficient prologue
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  bwd_apply_fused_kernel<<<(int)blocks, NT, 0, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial,
+                                                                    nblk, fin, dy, R, C, unshuffle_H, unshuffle_W);
+  SST_LAUNCH_CHECK("bwd_apply_fused_kernel");
+  return SST_OK;
 }
 
 SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean, const float* rstd,

@@ -66,3 +66,21 @@ __device__ __forceinline__ void acquire_after_ticket() {
 __device__ __forceinline__ float load_agent(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Last-arriver total of per-workgroup partials (fixed order => reproducible).  Call from ALL threads of the
+// workgroup after thread 0 has stored partials[blockIdx] (plain store).  Returns true in the last-arriving
+// workgroup, where `total` (valid in every thread) is the sum of partials[0..nblk).  `s_flag`/`red` are LDS.
+template <int NT>
+__device__ __forceinline__ bool last_block_total(const float* partials, unsigned* counter, unsigned nblk, unsigned* s_flag,
+                                                 float* red, float& total) {
+  if (threadIdx.x == 0) *s_flag = (publish_and_ticket(counter) == nblk - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!*s_flag) return false;
+  if (threadIdx.x == 0) acquire_after_ticket();
+  __syncthreads();
+  float t = 0.f;
+  for (unsigned i = threadIdx.x; i < nblk; i += NT) t += load_agent(partials + i);
+  total = block_sum<NT>(t, red);
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}

@@ -51,14 +51,14 @@ __global__ __launch_bounds__(NT) void clamp_bwd_kernel(const float* __restrict__
   }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C,
-                                       int accumulate) {
-  const int c = threadIdx.x;
-  if (c < C) {
-    float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += partial[(size_t)b * C + c];
-    out[c] = accumulate ? out[c] + t : t;
-  }
+__global__ __launch_bounds__(NT) void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             int nblk, int C, int accumulate) {
+  __shared__ float red[NT / 64];
+  const int c = blockIdx.x;
+  float t = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += NT) t += partial[(size_t)b * C + c];
+  t = block_sum<NT>(t, red);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + t : t;
 }
 
 // ---- pixel criterion: mode 0 = MSE, 1 = L1.  Two-stage fixed-order reduction (last block finishes).
@@ -83,17 +83,10 @@ __global__ __launch_bounds__(NT) void pixel_loss_fwd_kernel(const float* __restr
     }
   }
   s = block_sum<NT>(s, red);
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = s;
-    const unsigned t = publish_and_ticket(counter);
-    if (t == gridDim.x - 1) {
-      acquire_after_ticket();
-      float tot = 0.f;
-      for (unsigned i = 0; i < gridDim.x; ++i) tot += load_agent(partials + i);
-      loss[0] = tot / (float)n;
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  __shared__ unsigned s_flag;
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+  float tot;
+  if (last_block_total<NT>(partials, counter, gridDim.x, &s_flag, red, tot) && threadIdx.x == 0) loss[0] = tot / (float)n;
 }
 
 // dx (+)= scale * d loss/dx ;  scale = scale_host * (scale_dev ? *scale_dev : 1)
@@ -165,13 +158,16 @@ SST_API int sst_clamp_bwd(const float* g, const float* pre, float* out, float* p
   clamp_bwd_kernel<<<nb, NT, 0, sst_stream(stream)>>>(g, pre, out, partial, B, C, H, W);
   SST_LAUNCH_CHECK("clamp_bwd_kernel");
   if (dbias) {
-    colsum_finalize_kernel<<<1, 64, 0, sst_stream(stream)>>>(partial, dbias, nb, C, accumulate);
+    colsum_finalize_kernel<<<C, NT, 0, sst_stream(stream)>>>(partial, dbias, nb, C, accumulate);
     SST_LAUNCH_CHECK("colsum_finalize_kernel");
   }
   return SST_OK;
 }
 
-SST_API int sst_pixel_loss_blocks(int64_t n) { return grid_for(n / 4 + 1); }
+SST_API int sst_pixel_loss_blocks(int64_t n) {
+  const int b = grid_for(n / 4 + 1);
+  return b > 256 ? 256 : b;
+}
 
 SST_API int sst_pixel_loss_fwd(const float* x, const float* gt, float* loss, float* partials, unsigned* counter, int64_t n,
                                int mode, void* stream) {

@@ -205,19 +205,13 @@ __global__ __launch_bounds__(NT) void st_loss_fwd_kernel(const float* __restrict
     gS[o + 2 * hw] = gc;
   }
   const float bsum = block_sum<NT>(lsum, red);
-  if (threadIdx.x == 0) {
-    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned me = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    partials[me] = bsum;
-    const unsigned t = publish_and_ticket(counter);
-    if (t == nblk - 1) {  // last arriver: fixed-order sum => run-to-run reproducible
-      acquire_after_ticket();
-      float tot = 0.f;
-      for (unsigned i = 0; i < nblk; ++i) tot += load_agent(partials + i);
-      loss[0] = tot / ((float)B * (float)H * (float)W);
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  __shared__ unsigned s_flag;
+  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned me = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (threadIdx.x == 0) partials[me] = bsum;
+  float tot;
+  if (last_block_total<NT>(partials, counter, nblk, &s_flag, red, tot) && threadIdx.x == 0)
+    loss[0] = tot / ((float)B * (float)H * (float)W);
 }
 
 // ---------------------------------------------------------------------------------------------

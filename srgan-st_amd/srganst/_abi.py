@@ -38,6 +38,10 @@ SIGNATURES = {
     "sst_bn_residual": (c_int, [P, P, P, P, P, P, c_int64, c_int, P]),
     "sst_bwd_reduce_blocks": (c_int, [c_int64, c_int]),
     "sst_bwd_reduce": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P]),
+    "sst_bwd_reduce_blocks_small": (c_int, [c_int64, c_int]),
+    "sst_bwd_reduce_small": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P]),
+    "sst_bwd_apply_fused": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int, c_float, P, P, P, P, P, P, c_int, P, c_int64,
+                                    c_int, c_int, c_int, P]),
     "sst_bwd_finalize": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P]),
     "sst_bwd_apply": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     "sst_add": (c_int, [P, P, P, c_int64, P]),

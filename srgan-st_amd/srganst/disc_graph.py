@@ -89,12 +89,11 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
             gam = p[f"features.{bi}.weight"]
             dg = G(f"features.{bi}.weight") if wg else torch.empty_like(gam)
             db = G(f"features.{bi}.bias") if wg else torch.empty_like(gam)
-            cA, cB, cC = ops.bwd_reduce_finalize(g, y, n, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1,
-                                                 mean=r["mean"], rstd=r["rstd"], gamma=gam, dgamma=dg, dbeta=db)
-            dy = ops.bwd_apply(g, y, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1, cA=cA, cB=cB, cC=cC)
+            dy = ops.bwd_reduce_apply(g, y, n, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1,
+                                      mean=r["mean"], rstd=r["rstd"], gamma=gam, dgamma=dg, dbeta=db)
+        elif wg:
+            dy = ops.bwd_reduce_apply(g, y, n, slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"))
         else:
-            if wg:
-                ops.bwd_reduce_finalize(g, y, n, slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"))
             dy = ops.bwd_apply(g, y, slope_const=LRELU, act=1)
         if wg:
             dwc = G(f"features.{ci}.weight")

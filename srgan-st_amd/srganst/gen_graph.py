@@ -150,8 +150,8 @@ def backward(module, params, sv, dsr, need_dx=False):
         pre = f"upsampling.{j}.upsample_block"
         u_in, slope_in, us = sv["ups"][j]
         sl = p[pre + ".2.weight"]
-        ops.bwd_reduce_finalize(g, us, rows(us), slope=sl, act=1, dslope=grads[pre + ".2.weight"])
-        du = ops.bwd_apply(g, us, slope=sl, act=1, unshuffle=True)                  # [B,h,w,4C] pre-shuffle grad
+        du = ops.bwd_reduce_apply(g, us, rows(us), slope=sl, act=1, dslope=grads[pre + ".2.weight"],
+                                  unshuffle=True)                                    # [B,h,w,4C] pre-shuffle grad
         ops.bwd_reduce_finalize(du, du, rows(du), dbeta=grads[pre + ".0.bias"])
         with ops.SideStream(u_in, du, grads[pre + ".0.weight"]):
             ops.conv_wgrad(u_in, du, grads[pre + ".0.weight"], 3, 1, in_slope=slope_in,
@@ -160,9 +160,8 @@ def backward(module, params, sv, dsr, need_dx=False):
     # ---- u = BN(conv2(h_last)) + PReLU(z1)
     y3, m3, r3, s3, t3 = sv["conv2"]
     n = rows(y3)
-    cA, cB, cC = ops.bwd_reduce_finalize(g, y3, n, scale=s3, shift=t3, mean=m3, rstd=r3, gamma=p["conv2.1.weight"],
-                                         dgamma=grads["conv2.1.weight"], dbeta=grads["conv2.1.bias"])
-    dy3 = ops.bwd_apply(g, y3, cA=cA, cB=cB, cC=cC)
+    dy3 = ops.bwd_reduce_apply(g, y3, n, scale=s3, shift=t3, mean=m3, rstd=r3, gamma=p["conv2.1.weight"],
+                               dgamma=grads["conv2.1.weight"], dbeta=grads["conv2.1.bias"])
     with ops.SideStream(sv["h_last"], dy3, grads["conv2.0.weight"]):
         ops.conv_wgrad(sv["h_last"], dy3, grads["conv2.0.weight"], 3, 1,
                        in_slope=a1 if not sv["blocks"] else None, in_act=ACT_SLOPE if not sv["blocks"] else 0)
@@ -174,24 +173,22 @@ def backward(module, params, sv, dsr, need_dx=False):
         first = i == 0
         h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2 = sv["blocks"][i]
         sl = p[pre + ".2.weight"]
-        cA, cB, cC = ops.bwd_reduce_finalize(dh, y2, n, scale=s2, shift=t2, mean=m2, rstd=r2, gamma=p[pre + ".4.weight"],
-                                             dgamma=grads[pre + ".4.weight"], dbeta=grads[pre + ".4.bias"])
-        dy2 = ops.bwd_apply(dh, y2, cA=cA, cB=cB, cC=cC)
+        dy2 = ops.bwd_reduce_apply(dh, y2, n, scale=s2, shift=t2, mean=m2, rstd=r2, gamma=p[pre + ".4.weight"],
+                                   dgamma=grads[pre + ".4.weight"], dbeta=grads[pre + ".4.bias"])
         with ops.SideStream(y1, dy2, grads[pre + ".3.weight"]):
             ops.conv_wgrad(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
         dp1 = ops.conv_fwd(dy2, wd[pre + ".3.weight"], C, 3, 1)[0]
-        cA, cB, cC = ops.bwd_reduce_finalize(dp1, y1, n, scale=s1, shift=t1, slope=sl, act=1, mean=m1, rstd=r1,
-                                             gamma=p[pre + ".1.weight"], dgamma=grads[pre + ".1.weight"],
-                                             dbeta=grads[pre + ".1.bias"], dslope=grads[pre + ".2.weight"])
-        dy1 = ops.bwd_apply(dp1, y1, scale=s1, shift=t1, slope=sl, act=1, cA=cA, cB=cB, cC=cC)
+        dy1 = ops.bwd_reduce_apply(dp1, y1, n, scale=s1, shift=t1, slope=sl, act=1, mean=m1, rstd=r1,
+                                   gamma=p[pre + ".1.weight"], dgamma=grads[pre + ".1.weight"],
+                                   dbeta=grads[pre + ".1.bias"], dslope=grads[pre + ".2.weight"])
         with ops.SideStream(h, dy1, grads[pre + ".0.weight"]):
             ops.conv_wgrad(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None,
                            in_act=ACT_SLOPE if first else 0)
         dh = ops.conv_fwd(dy1, wd[pre + ".0.weight"], C, 3, 1, residual=dh)[0]
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
-    ops.bwd_reduce_finalize(dh, z1, n, g2=dskip, slope=a1, act=1, dbeta=grads["conv1.0.bias"], dslope=grads["conv1.1.weight"])
-    dz1 = ops.bwd_apply(dh, z1, g2=dskip, slope=a1, act=1)
+    dz1 = ops.bwd_reduce_apply(dh, z1, n, g2=dskip, slope=a1, act=1, dbeta=grads["conv1.0.bias"],
+                               dslope=grads["conv1.1.weight"])
     with ops.SideStream(dz1, sv["x3"], grads["conv1.0.weight"]):
         if fast9:
             ops.wgrad_c3(dz1, sv["x3"], grads["conv1.0.weight"], 1)

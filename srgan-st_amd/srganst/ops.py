@@ -468,3 +468,26 @@ def conv9_to3_fwd(x, w, bias=None, in_slope=None, in_slope_const=0.0, in_act=ACT
                                        int(in_act), B, H, W, C, stream_ptr()), "sst_conv9_to3_fwd")
     _prof_end(e0, "conv9_to3_fwd_kernel", 2.0 * B * H * W * C * 3 * 81)
     return y, y_pre
+
+
+def bwd_reduce_apply(g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
+                     gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False):
+    """Backward through [BatchNorm ->] activation in two launches: a few-workgroup reduction, then the apply kernel
+    whose workgroups derive the BN-backward coefficients from the raw partials themselves (workgroup 0 also writes
+    dgamma / dbeta / dslope).  Returns dy (pre-PixelShuffle layout when unshuffle)."""
+    C = y.shape[-1]
+    R = y.numel() // C
+    nblk = _abi.lib().sst_bwd_reduce_blocks_small(R, C)
+    partial = _f32(nblk, 3, C, like=y)
+    check(_abi.lib().sst_bwd_reduce_small(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
+                                          ptr(partial), R, C, stream_ptr()), "sst_bwd_reduce_small")
+    uh = uw = 0
+    if unshuffle:
+        B, uh, uw, _ = y.shape
+        dy = _f32(B, uh // 2, uw // 2, 4 * C, like=y)
+    else:
+        dy = torch.empty_like(y)
+    check(_abi.lib().sst_bwd_apply_fused(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
+                                         ptr(partial), nblk, float(n), ptr(mean), ptr(rstd), ptr(gamma), ptr(dgamma), ptr(dbeta),
+                                         ptr(dslope), int(accumulate), ptr(dy), R, C, uh, uw, stream_ptr()), "sst_bwd_apply_fused")
+    return dy
