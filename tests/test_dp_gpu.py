@@ -1,0 +1,106 @@
+"""GPU, 2 ranks sharing the one test GPU (gloo carries the collective; RCCL refuses two ranks on one device):
+the data-parallel engine path - [fwd+bwd graph] -> gradient all-reduce -> [optimizer graph] - end to end.
+Parity statement: after each step every rank holds the parameters a single process would get from
+the MEAN of the per-rank gradients; BatchNorm statistics stay rank-local."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make(seed=3):
+    from srganst.config import Config
+    from srganst.model import Generator
+    cfg = Config()
+    cfg.MODEL.G_N_CHANNEL, cfg.MODEL.G_N_RCB = 16, 2
+    torch.manual_seed(seed)
+    return cfg, Generator(cfg).cuda().train()
+
+
+def _batch(rank, step):
+    g = torch.Generator().manual_seed(1000 * rank + step)
+    return torch.rand(2, 3, 32, 32, generator=g).cuda(), torch.rand(2, 3, 8, 8, generator=g).cuda()
+
+
+def _worker(rank, world, port, use_graph, q):
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "srgan-st_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from srganst import dist as sdist
+    from srganst.engine import WarmupEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    sdist.init_from_env("gloo")
+    cfg, G = _make(seed=3 + rank)                       # different init per rank ...
+    sdist.broadcast_module(G)                           # ... made identical
+    eng = WarmupEngine(cfg, G, {"Pixel": MSELoss(), "ST": StructureTensorLoss()}, {"Pixel": 1.0, "ST": 1 / 3},
+                       use_graph=use_graph, adam_capturable=True)
+    assert eng.world == 2
+    for step in range(4):
+        eng.step(*_batch(rank, step))
+    torch.cuda.synchronize()
+    q.put((rank, {k: v.cpu().numpy() for k, v in G.state_dict().items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_dp_world2_matches_mean_gradient_step(use_graph):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in res.items()}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # parameters identical on both ranks; BN running stats are rank-local (different data)
+    for k in res[0]:
+        if "running" in k or "num_batches" in k:
+            continue
+        assert torch.equal(res[0][k], res[1][k]), k
+    assert not torch.equal(res[0]["trunk.0.rcb.1.running_mean"], res[1]["trunk.0.rcb.1.running_mean"])
+
+    # single-process emulation: per-rank forward/backward on a replica carrying that rank's BN buffers, mean gradient,
+    # one Adam on the shared parameters
+    from srganst.engine import make_adam
+    from srganst.loss import MSELoss, StructureTensorLoss
+    cfg, G0 = _make(seed=3)                             # rank 0's init == the broadcast state
+    _, G1 = _make(seed=3)
+    G1.load_state_dict(G0.state_dict())
+    opt = make_adam(G0.parameters(), 1e-4, (0.9, 0.999), 1e-4, 0, capturable=True)
+    mse, st = MSELoss(), StructureTensorLoss()
+    for step in range(4):
+        grads = []
+        for rank, G in enumerate((G0, G1)):
+            G.zero_grad()
+            gt, lr = _batch(rank, step)
+            sr = G(lr)
+            (mse(sr, gt) + st(sr, gt) * (1 / 3)).backward()
+            grads.append([p.grad.clone() for p in G.parameters()])
+        for p, a, b in zip(G0.parameters(), *grads):
+            p.grad = (a + b) * 0.5
+        opt.step()
+        with torch.no_grad():
+            for p0, p1 in zip(G0.parameters(), G1.parameters()):
+                p1.copy_(p0)
+    for k, v in G0.state_dict().items():
+        if "num_batches" in k:
+            continue
+        assert torch.allclose(v.cpu(), res[0][k], rtol=1e-5, atol=1e-7), k
+    for k, v in G1.state_dict().items():
+        if "running" in k:
+            assert torch.allclose(v.cpu(), res[1][k], rtol=1e-5, atol=1e-7), k
