@@ -59,31 +59,57 @@ def build_engine(workload, device, use_graph, hr):
 
 
 def kernel_roofline(workload, device, hr, B):
-    """Per-launch timing (HIP events on the launch stream) of the MFMA kernels over two eager steps."""
+    """Live HIP-event timing of the MFMA conv kernels: one eager step records every launch of a kernel family
+    (same pointers, same shapes); each family is then replayed back-to-back from a hipGraph on the launch stream
+    (GPU-bound: no host gaps inside the timed region), bracketed by HIP events.  The family with the largest
+    time share is reported against the fp32 MFMA peak."""
     from srganst import ops
     eng, _ = build_engine(workload, device, use_graph=False, hr=hr)
     gt, lr = synth_batch(B, hr, device, 1)
+    saved_overlap, ops.OVERLAP = ops.OVERLAP, False
     eng.step(gt, lr)
     torch.cuda.synchronize()
-    ops.PROFILE = []
-    for _ in range(3):
-        eng.step(gt, lr)
+    ops.TRACE = {}
+    eng.step(gt, lr)
     torch.cuda.synchronize()
-    agg = {}
-    for name, flops, e0, e1 in ops.PROFILE:
-        a = agg.setdefault(name, [0.0, 0.0, 0])
-        a[0] += flops
-        a[1] += e0.elapsed_time(e1) * 1e-3
-        a[2] += 1
-    ops.PROFILE = None
-    rows = {k: {"launches_per_step": v[2] // 3, "avg_us": v[1] / v[2] * 1e6, "tflops": v[0] / v[1] / 1e12,
-                "time_share_ms_per_step": v[1] / 3 * 1e3} for k, v in agg.items()}
-    dom = max(agg, key=lambda k: agg[k][1])
-    a = agg[dom]
-    roof = {"bound": "mfma", "kernel": dom, "achieved": a[0] / a[1] / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": a[0] / a[1] / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-            "avg_launch_us": a[1] / a[2] * 1e6, "flop_per_launch": a[0] / a[2], "kernels": rows}
-    return roof
+    trace, ops.TRACE = ops.TRACE, None
+    ops.OVERLAP = saved_overlap
+    rows = {}
+    for name, calls in trace.items():
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for fn, _, _ in calls:
+                fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for fn, _, _ in calls:
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps                      # seconds for one step's worth of this family
+        flops = sum(f for _, f, _ in calls)
+        rows[name] = {"launches_per_step": len(calls), "avg_launch_us": t / len(calls) * 1e6, "tflops": flops / t / 1e12,
+                      "ms_per_step": t * 1e3, "flop_per_launch": flops / len(calls)}
+    dom = max(rows, key=lambda k: rows[k]["ms_per_step"])
+    r = rows[dom]
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes (see DESIGN.md 7)
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(dom)
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": dom, "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_us": r["avg_launch_us"],
+            "flop_per_launch": r["flop_per_launch"], "launches_per_step": r["launches_per_step"], "kernels": rows}
 
 
 def cpu_baseline(workload, B, hr, budget_s=20.0):
@@ -112,7 +138,7 @@ def cpu_baseline(workload, B, hr, budget_s=20.0):
         fn(gt, lr)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 40:
+        if el > budget_s or n >= 400:
             break
     return {"value": B * n / el, "unit": "HR images/s", "cores": threads, "kind": "port",
             "sample": f"{n} steps of the same B={B} {hr}px step through oracle/ (torch CPU eager, {threads} threads), {el:.1f} s"}

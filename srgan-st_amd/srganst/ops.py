@@ -20,6 +20,17 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 PROFILE = None
 
 
+# --- optional launch trace (bench.py roofline leg): kernel name -> list of (relaunch closure, flops).  The closures
+# hold their tensors alive and re-issue exactly the same launch, so a kernel family can be replayed back-to-back
+# from a hipGraph (GPU-bound timing, no host gaps).
+TRACE = None
+
+
+def _trace(name, flops, fn, *keep):
+    if TRACE is not None:
+        TRACE.setdefault(name, []).append((fn, flops, keep))
+
+
 def _prof_begin():
     if PROFILE is None:
         return None
@@ -76,10 +87,13 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
         stats = _f32(mt, 2, cout, like=x)
         cnt = _f32(mt, like=x)
     e0 = _prof_begin()
-    check(_abi.lib().sst_conv_fwd(ptr(x), ptr(wp), ptr(y), ptr(y_pre), ptr(bias), ptr(in_scale), ptr(in_shift),
-                                  ptr(in_slope), float(in_slope_const), int(in_act), ptr(residual), ptr(stats), ptr(cnt),
-                                  int(out_mode), B, H, W, cin, cout, ksize, stride, stream_ptr()), "sst_conv_fwd")
-    _prof_end(e0, f"conv_fwd_kernel<{ksize},{stride}>", 2.0 * B * ho * wo * cout * cin * ksize * ksize)
+    args = (ptr(x), ptr(wp), ptr(y), ptr(y_pre), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const),
+            int(in_act), ptr(residual), ptr(stats), ptr(cnt), int(out_mode), B, H, W, cin, cout, ksize, stride)
+    check(_abi.lib().sst_conv_fwd(*args, stream_ptr()), "sst_conv_fwd")
+    flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
+    _prof_end(e0, f"conv_fwd_kernel<{ksize},{stride}>", flops)
+    _trace(f"conv_fwd_kernel<{ksize},{stride}>", flops, lambda: _abi.lib().sst_conv_fwd(*args, stream_ptr()),
+           x, wp, y, y_pre, bias, in_scale, in_shift, in_slope, residual, stats, cnt)
     return y, y_pre, stats, cnt
 
 
@@ -93,10 +107,13 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
     nch = _abi.lib().sst_conv_wgrad_chunks(B, ho, wo, cin, cout, ksize)
     slab = _f32(nch * ksize * ksize * cout * cin, like=x)
     e0 = _prof_begin()
-    check(_abi.lib().sst_conv_wgrad(ptr(x), ptr(dy), ptr(slab), ptr(dw_out), ptr(in_scale), ptr(in_shift), ptr(in_slope),
-                                    float(in_slope_const), int(in_act), B, H, W, cin, cout, stride, ksize,
-                                    int(accumulate), stream_ptr()), "sst_conv_wgrad")
-    _prof_end(e0, "conv_wgrad_kernel+reduce", 2.0 * B * ho * wo * cout * cin * ksize * ksize)
+    args = (ptr(x), ptr(dy), ptr(slab), ptr(dw_out), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const),
+            int(in_act), B, H, W, cin, cout, stride, ksize, int(accumulate))
+    check(_abi.lib().sst_conv_wgrad(*args, stream_ptr()), "sst_conv_wgrad")
+    flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
+    _prof_end(e0, "conv_wgrad_kernel+reduce", flops)
+    _trace("conv_wgrad_kernel+wgrad_reduce_kernel", flops, lambda: _abi.lib().sst_conv_wgrad(*args, stream_ptr()),
+           x, dy, slab, dw_out, in_scale, in_shift, in_slope)
     return dw_out
 
 
