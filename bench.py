@@ -5,7 +5,8 @@
 
 N=1 workload (default): BASELINE.json configs[1] - SRResNet x4, 96 px HR crops, B=16 per GPU,
 pixel(MSE) + structure-tensor/3 loss, one full optimisation step (G fwd, losses, G bwd, Adam).
-`--workload srgan` = configs[2] without the VGG content term (G + D + adversarial + pixel + ST, D updated every step).
+`--workload srgan` = configs[2] without the VGG content term (G + D + adversarial + pixel + ST, D updated every step);
+`--workload srgan_vgg` = configs[2] with it (seeded-random VGG19: the ImageNet weights are a network fetch).
 Prints ONE JSON line (rank 0).  Inputs are synthetic DIV2K-shaped tensors already resident in HBM.
 """
 import argparse
@@ -52,6 +53,9 @@ def build_engine(workload, device, use_graph, hr):
         return WarmupEngine(cfg, G, crits, w, use_graph=use_graph), cfg
     D = Discriminator(cfg).to(device).train()
     G = Generator(cfg).to(device).train()
+    if workload == "srgan_vgg":
+        from srganst.loss import ContentLossVGG
+        cfg.add_g_criterion("ContentVGG", ContentLossVGG(cfg), 1.0)     # seeded-random VGG19 (ImageNet weights are a fetch)
     cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
     cfg.add_g_criterion("ST", StructureTensorLoss(), 1.0 / 3.0)
     cfg.SOLVER.D_UPDATE_INTERVAL = 1
@@ -126,6 +130,14 @@ def cpu_baseline(workload, B, hr, budget_s=20.0):
     if workload == "srresnet":
         tr = osteps.OracleTrainer(om.init_generator_state(), criterions=(("Pixel", 1.0), ("ST", 1.0 / 3.0)))
         fn = tr.warmup_step
+    elif workload == "srgan_vgg":
+        from oracle import vgg as ovgg
+        vsd = ovgg.init_vgg_state(0)
+        d0 = om.init_discriminator_state(image_size=hr)
+        tr = osteps.OracleTrainer(om.init_generator_state(), d0, criterions=(("Adversarial", 0.001), ("ContentVGG", 1.0), ("Pixel", 1.0),
+                                                                             ("ST", 1.0 / 3.0)),
+                                  d_update_interval=1, vgg=lambda sr, gt: ovgg.content_loss(vsd, sr, gt))
+        fn = tr.train_step
     else:
         d0 = om.init_discriminator_state(image_size=hr)
         tr = osteps.OracleTrainer(om.init_generator_state(), d0, criterions=(("Adversarial", 0.001), ("Pixel", 1.0), ("ST", 1.0 / 3.0)),
@@ -149,7 +161,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="srresnet", choices=["srresnet", "srgan"])
+    ap.add_argument("--workload", default="srresnet", choices=["srresnet", "srgan", "srgan_vgg"])
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--hr", type=int, default=96)
     ap.add_argument("--no-graph", action="store_true")
@@ -201,9 +213,12 @@ def main():
         if args.workload == "srresnet":
             flop_img = 3 * 2 * G_FWD_MAC_PER_IMG
             wl = "srresnet_x4_hr96_b16_mse+st (BASELINE configs[1])"
-        else:
+        elif args.workload == "srgan":
             flop_img = 2 * (3 * G_FWD_MAC_PER_IMG + 2 * D_FWD_MAC_PER_IMG + 6 * D_FWD_MAC_PER_IMG)
             wl = "srgan_x4_hr96_b16_adv+mse+st_D-every-step (BASELINE configs[2] minus VGG content)"
+        else:
+            flop_img = 2 * (3 * G_FWD_MAC_PER_IMG + 2 * D_FWD_MAC_PER_IMG + 6 * D_FWD_MAC_PER_IMG + 3 * 3583.18e6)
+            wl = "srgan_x4_hr96_b16_adv+vgg(random weights)+mse+st_D-every-step (BASELINE configs[2])"
         if args.hr != 96:
             wl = wl.replace("hr96", f"hr{args.hr}")
             flop_img *= (args.hr / 96.0) ** 2

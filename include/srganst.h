@@ -132,6 +132,12 @@ int sst_slab_reduce(const float* slabs, float* out, int nslab, int64_t n, int ac
  * clamp_(0,1) model.py:150 fused with the NCHW->NHWC hand-off and the conv3 bias gradient.
  * pixel criterion config.py:88-90 (mode 0 MSE / 1 L1); BCEWithLogits config.py:71-73, train.py:113-161. */
 int sst_transpose(const float* src, float* dst, int B, int C, int H, int W, int to_nchw, void* stream);
+/* VGG19 feature stack pieces of ContentLossVGG (loss.py:11-70): ImageNet normalise fused with the layout change,
+ * ReLU+MaxPool2d(2) forward/backward; the feature criterion is sst_pixel_loss_* with mode |= 2 (criterion on relu(x)). */
+int sst_transpose_affine(const float* src, float* dst, int B, int C, int H, int W, int to_nchw,
+                         const float* scale, const float* shift, void* stream);
+int sst_maxpool_relu_fwd(const float* y, float* out, int B, int H, int W, int C, void* stream);
+int sst_maxpool_relu_bwd(const float* g, const float* y, float* dy, int B, int H, int W, int C, void* stream);
 int sst_clamp_bwd_blocks(int B, int H, int W);
 int sst_clamp_bwd(const float* g, const float* pre, float* out, float* partial, float* dbias,
                   int accumulate, int B, int C, int H, int W, void* stream);

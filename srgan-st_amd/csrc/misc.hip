@@ -11,19 +11,84 @@ namespace {
 constexpr int NT = 256;
 
 // dst NHWC [B,H,W,C] <- src NCHW [B,C,H,W]   (dir 0)   or the inverse (dir 1).  Small C (3): plain gather.
+// optional per-channel affine v*sc[c] + sh[c] (ImageNet normalisation of loss.py:52 and its backward)
 __global__ __launch_bounds__(NT) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C,
-                                                       int H, int W, int dir) {
+                                                       int H, int W, int dir, const float* __restrict__ sc,
+                                                       const float* __restrict__ sh) {
   const int64_t total = (int64_t)B * C * H * W, hw = (int64_t)H * W;
   for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    int c;
+    float v;
     if (dir == 0) {  // i indexes dst NHWC
-      const int c = (int)(i % C);
+      c = (int)(i % C);
       const int64_t p = i / C, b = p / hw, r = p - b * hw;
-      dst[i] = src[(b * C + c) * hw + r];
+      v = src[(b * C + c) * hw + r];
     } else {         // i indexes dst NCHW
       const int64_t r = i % hw, bc = i / hw, b = bc / C;
-      const int c = (int)(bc - b * C);
-      dst[i] = src[(b * hw + r) * C + c];
+      c = (int)(bc - b * C);
+      v = src[(b * hw + r) * C + c];
     }
+    if (sc) v = fmaf(v, sc[c], sh ? sh[c] : 0.f);
+    dst[i] = v;
+  }
+}
+
+// out[b,oy,ox,c] = max over the 2x2 window of relu(y[b,2oy+i,2ox+j,c])      (nn.ReLU + nn.MaxPool2d(2) of VGG19)
+__global__ __launch_bounds__(NT) void maxpool_relu_fwd_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int H,
+                                                              int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
+  const int64_t total = (int64_t)B * Ho * Wo * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int c4 = (int)(i % c4n);
+    int64_t p = i / c4n;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int64_t b = p / Ho;
+    const f32x4* src = reinterpret_cast<const f32x4*>(y) + (((b * H + 2 * oy) * W + 2 * ox) * (int64_t)c4n + c4);
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};   // relu: max with 0
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 v = src[((k >> 1) * W + (k & 1)) * (int64_t)c4n];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+    }
+    reinterpret_cast<f32x4*>(out)[i] = m;
+  }
+}
+
+// dy[b,y,x,c] = g[b,y/2,x/2,c] if (y,x) is the first arg-max of relu(y) in its window and y > 0, else 0
+__global__ __launch_bounds__(NT) void maxpool_relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                              float* __restrict__ dy, int B, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
+  const int64_t total = (int64_t)B * Ho * Wo * c4n;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int c4 = (int)(i % c4n);
+    int64_t p = i / c4n;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int64_t b = p / Ho;
+    const int64_t base = ((b * H + 2 * oy) * W + 2 * ox) * (int64_t)c4n + c4;
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const f32x4*>(y)[base + ((k >> 1) * W + (k & 1)) * (int64_t)c4n];
+    f32x4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int arg = 0;
+      float m = fmaxf(v[0][j], 0.f);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float r = fmaxf(v[k][j], 0.f);
+        if (r > m) { m = r; arg = k; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][j] = (k == arg && v[k][j] > 0.f) ? gv[j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<f32x4*>(dy)[base + ((k >> 1) * W + (k & 1)) * (int64_t)c4n] = o[k];
   }
 }
 
@@ -64,21 +129,23 @@ __global__ __launch_bounds__(NT) void colsum_finalize_kernel(const float* __rest
 // ---- pixel criterion: mode 0 = MSE, 1 = L1.  Two-stage fixed-order reduction (last block finishes).
 __global__ __launch_bounds__(NT) void pixel_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gt,
                                                             float* __restrict__ loss, float* __restrict__ partials,
-                                                            unsigned* __restrict__ counter, int64_t n, int mode) {
+                                                            unsigned* __restrict__ counter, int64_t n, int mode_) {
   __shared__ float red[NT / 64];
+  const int mode = mode_ & 1;
+  const bool relu = (mode_ & 2) != 0;   // criterion on relu(x), relu(gt): VGG feature taps (loss.py:66-68)
   float s = 0.f;
   const int64_t n4 = n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
     const f32x4 a = reinterpret_cast<const f32x4*>(x)[i], b = reinterpret_cast<const f32x4*>(gt)[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float d = a[j] - b[j];
+      const float d = relu ? fmaxf(a[j], 0.f) - fmaxf(b[j], 0.f) : a[j] - b[j];
       s += mode == 0 ? d * d : fabsf(d);
     }
   }
   if (blockIdx.x == 0) {
     for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += NT) {
-      const float d = x[i] - gt[i];
+      const float d = relu ? fmaxf(x[i], 0.f) - fmaxf(gt[i], 0.f) : x[i] - gt[i];
       s += mode == 0 ? d * d : fabsf(d);
     }
   }
@@ -92,12 +159,15 @@ __global__ __launch_bounds__(NT) void pixel_loss_fwd_kernel(const float* __restr
 // dx (+)= scale * d loss/dx ;  scale = scale_host * (scale_dev ? *scale_dev : 1)
 __global__ __launch_bounds__(NT) void pixel_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gt,
                                                             float* __restrict__ dx, const float* __restrict__ scale_dev,
-                                                            float scale_host, int accumulate, int64_t n, int mode) {
+                                                            float scale_host, int accumulate, int64_t n, int mode_) {
+  const int mode = mode_ & 1;
+  const bool relu = (mode_ & 2) != 0;
   float sc = scale_host / (float)n;
   if (scale_dev) sc *= scale_dev[0];
   for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-    const float d = x[i] - gt[i];
-    const float g = mode == 0 ? 2.f * d * sc : (d > 0.f ? sc : (d < 0.f ? -sc : 0.f));
+    const float d = relu ? fmaxf(x[i], 0.f) - fmaxf(gt[i], 0.f) : x[i] - gt[i];
+    float g = mode == 0 ? 2.f * d * sc : (d > 0.f ? sc : (d < 0.f ? -sc : 0.f));
+    if (relu && !(x[i] > 0.f)) g = 0.f;
     dx[i] = accumulate ? dx[i] + g : g;
   }
 }
@@ -143,8 +213,32 @@ inline int grid_for(int64_t items) {
 // ------------------------------------------------------------------------------------------ C ABI
 SST_API int sst_transpose(const float* src, float* dst, int B, int C, int H, int W, int to_nchw, void* stream) {
   SST_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "sst_transpose: bad argument");
-  transpose_kernel<<<grid_for((int64_t)B * C * H * W), NT, 0, sst_stream(stream)>>>(src, dst, B, C, H, W, to_nchw);
+  transpose_kernel<<<grid_for((int64_t)B * C * H * W), NT, 0, sst_stream(stream)>>>(src, dst, B, C, H, W, to_nchw, nullptr, nullptr);
   SST_LAUNCH_CHECK("transpose_kernel");
+  return SST_OK;
+}
+
+// NCHW <-> NHWC with a per-channel affine v*scale[c] + shift[c] (shift may be null)
+SST_API int sst_transpose_affine(const float* src, float* dst, int B, int C, int H, int W, int to_nchw, const float* scale,
+                                 const float* shift, void* stream) {
+  SST_REQUIRE(src && dst && scale && B > 0 && C > 0 && H > 0 && W > 0, "sst_transpose_affine: bad argument");
+  transpose_kernel<<<grid_for((int64_t)B * C * H * W), NT, 0, sst_stream(stream)>>>(src, dst, B, C, H, W, to_nchw, scale, shift);
+  SST_LAUNCH_CHECK("transpose_kernel");
+  return SST_OK;
+}
+
+// ReLU + MaxPool2d(2) of the VGG19 feature stack (loss.py:46-49), NHWC, C % 4 == 0, H and W even
+SST_API int sst_maxpool_relu_fwd(const float* y, float* out, int B, int H, int W, int C, void* stream) {
+  SST_REQUIRE(y && out && B > 0 && H > 1 && W > 1 && !(H & 1) && !(W & 1) && C > 0 && !(C & 3), "sst_maxpool_relu_fwd: bad argument");
+  maxpool_relu_fwd_kernel<<<grid_for((int64_t)B * (H / 2) * (W / 2) * (C / 4)), NT, 0, sst_stream(stream)>>>(y, out, B, H, W, C);
+  SST_LAUNCH_CHECK("maxpool_relu_fwd_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_maxpool_relu_bwd(const float* g, const float* y, float* dy, int B, int H, int W, int C, void* stream) {
+  SST_REQUIRE(g && y && dy && B > 0 && H > 1 && W > 1 && !(H & 1) && !(W & 1) && C > 0 && !(C & 3), "sst_maxpool_relu_bwd: bad argument");
+  maxpool_relu_bwd_kernel<<<grid_for((int64_t)B * (H / 2) * (W / 2) * (C / 4)), NT, 0, sst_stream(stream)>>>(g, y, dy, B, H, W, C);
+  SST_LAUNCH_CHECK("maxpool_relu_bwd_kernel");
   return SST_OK;
 }
 
@@ -171,7 +265,7 @@ SST_API int sst_pixel_loss_blocks(int64_t n) {
 
 SST_API int sst_pixel_loss_fwd(const float* x, const float* gt, float* loss, float* partials, unsigned* counter, int64_t n,
                                int mode, void* stream) {
-  SST_REQUIRE(x && gt && loss && partials && counter && n > 0 && (mode == 0 || mode == 1), "sst_pixel_loss_fwd: bad argument");
+  SST_REQUIRE(x && gt && loss && partials && counter && n > 0 && mode >= 0 && mode <= 3, "sst_pixel_loss_fwd: bad argument");
   pixel_loss_fwd_kernel<<<sst_pixel_loss_blocks(n), NT, 0, sst_stream(stream)>>>(x, gt, loss, partials, counter, n, mode);
   SST_LAUNCH_CHECK("pixel_loss_fwd_kernel");
   return SST_OK;
@@ -179,7 +273,7 @@ SST_API int sst_pixel_loss_fwd(const float* x, const float* gt, float* loss, flo
 
 SST_API int sst_pixel_loss_bwd(const float* x, const float* gt, float* dx, const float* scale_dev, float scale_host,
                                int accumulate, int64_t n, int mode, void* stream) {
-  SST_REQUIRE(x && gt && dx && n > 0 && (mode == 0 || mode == 1), "sst_pixel_loss_bwd: bad argument");
+  SST_REQUIRE(x && gt && dx && n > 0 && mode >= 0 && mode <= 3, "sst_pixel_loss_bwd: bad argument");
   pixel_loss_bwd_kernel<<<grid_for(n), NT, 0, sst_stream(stream)>>>(x, gt, dx, scale_dev, scale_host, accumulate, n, mode);
   SST_LAUNCH_CHECK("pixel_loss_bwd_kernel");
   return SST_OK;

@@ -47,6 +47,9 @@ SIGNATURES = {
     "sst_add": (c_int, [P, P, P, c_int64, P]),
     "sst_slab_reduce": (c_int, [P, P, c_int, c_int64, c_int, P]),
     "sst_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_transpose_affine": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "sst_maxpool_relu_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "sst_maxpool_relu_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "sst_clamp_bwd_blocks": (c_int, [c_int, c_int, c_int]),
     "sst_clamp_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_pixel_loss_blocks": (c_int, [c_int64]),

@@ -1,6 +1,7 @@
 """Generator criterions on the HIP path.  Mirrors reference loss.py (criterion(sr, gt) -> 0-dim).
 
 StructureTensorLoss  <- reference loss.py:380-413 (+ utils.py:194-280), kernels csrc/st_loss.hip
+ContentLossVGG       <- reference loss.py:11-70, in vgg_loss.py (re-exported here)
 """
 from __future__ import annotations
 
@@ -149,3 +150,6 @@ class BCEWithLogitsLoss(nn.Module):
                                             "(reference train.py:113-114 uses full([B,1], 0.9) / zeros)")
                 self._label_cache = {key: t}
         return _BceFn.apply(logits, t)
+
+
+from .vgg_loss import ContentLossVGG  # noqa: E402,F401  (reference loss.py:11)

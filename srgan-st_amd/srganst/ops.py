@@ -508,3 +508,29 @@ def bwd_reduce_apply(g, y, n, g2=None, scale=None, shift=None, slope=None, slope
                                          ptr(partial), nblk, float(n), ptr(mean), ptr(rstd), ptr(gamma), ptr(dgamma), ptr(dbeta),
                                          ptr(dslope), int(accumulate), ptr(dy), R, C, uh, uw, stream_ptr()), "sst_bwd_apply_fused")
     return dy
+
+
+def transpose_affine(x, to_nchw: bool, scale, shift=None):
+    if to_nchw:
+        B, H, W, C = x.shape
+        out = _f32(B, C, H, W, like=x)
+    else:
+        B, C, H, W = x.shape
+        out = _f32(B, H, W, C, like=x)
+    check(_abi.lib().sst_transpose_affine(ptr(x), ptr(out), B, C, H, W, int(to_nchw), ptr(scale), ptr(shift), stream_ptr()),
+          "sst_transpose_affine")
+    return out
+
+
+def maxpool_relu_fwd(y):
+    B, H, W, C = y.shape
+    out = _f32(B, H // 2, W // 2, C, like=y)
+    check(_abi.lib().sst_maxpool_relu_fwd(ptr(y), ptr(out), B, H, W, C, stream_ptr()), "sst_maxpool_relu_fwd")
+    return out
+
+
+def maxpool_relu_bwd(g, y):
+    B, H, W, C = y.shape
+    dy = torch.empty_like(y)
+    check(_abi.lib().sst_maxpool_relu_bwd(ptr(g), ptr(y), ptr(dy), B, H, W, C, stream_ptr()), "sst_maxpool_relu_bwd")
+    return dy

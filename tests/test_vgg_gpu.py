@@ -1,0 +1,52 @@
+"""GPU parity of ContentLossVGG (HIP) against the CPU oracle restatement, with identical seeded weights.
+(Parity against the reference itself is unpinned: ImageNet weights are a network fetch - see oracle/vgg.py.)"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_maxpool_relu_and_relu_criterion():
+    from srganst import ops
+    g = torch.Generator().manual_seed(51)
+    y = torch.randn(2, 8, 12, 10, generator=g, dtype=torch.float64, requires_grad=True)
+    up = torch.randn(2, 8, 6, 5, generator=g)
+    F.max_pool2d(F.relu(y), 2).backward(up.double())
+    yn = y.detach().float().permute(0, 2, 3, 1).contiguous().cuda()
+    out = ops.maxpool_relu_fwd(yn)
+    assert torch.allclose(out.permute(0, 3, 1, 2).cpu().double(), F.max_pool2d(F.relu(y.detach()), 2), atol=1e-6)
+    dy = ops.maxpool_relu_bwd(up.permute(0, 2, 3, 1).contiguous().cuda(), yn)
+    assert rel_err(dy.permute(0, 3, 1, 2).cpu(), y.grad) < 1e-6
+    a = torch.randn(3, 5, 7, 8, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(3, 5, 7, 8, generator=g)
+    (F.mse_loss(F.relu(a), F.relu(b.double())) * 0.25).backward()
+    ad, bd = a.detach().float().cuda(), b.cuda()
+    l = ops.pixel_loss_fwd(ad, bd, 2, {})
+    assert abs(l.item() - F.mse_loss(F.relu(a.detach()), F.relu(b.double())).item()) < 1e-6
+    assert rel_err(ops.pixel_loss_bwd(ad, bd, 2, scale_host=0.25).cpu(), a.grad) < 1e-6
+
+
+def test_content_loss_vgg_vs_oracle():
+    from oracle import vgg as ovgg
+    from srganst.config import Config
+    from srganst.vgg_loss import ContentLossVGG
+    cfg = Config()
+    crit = ContentLossVGG(cfg, seed=7)
+    sd = {k: v.detach().cpu() for k, v in crit.state_dict().items() if k.startswith("features.")}
+    ref_sd = ovgg.init_vgg_state(seed=7)
+    for k in ref_sd:
+        assert torch.equal(sd[k], ref_sd[k]), k            # same seeded init as the oracle
+    g = torch.Generator().manual_seed(8)
+    gt = torch.rand(2, 3, 96, 96, generator=g)
+    x = (gt + 0.1 * torch.randn(2, 3, 96, 96, generator=g)).clamp(0, 1)
+    x64 = x.double().requires_grad_(True)
+    l64 = ovgg.content_loss(ref_sd, x64, gt.double(), cfg.MODEL.G_LOSS.VGG19_LAYERS)
+    l64.backward()
+    xg = x.cuda().requires_grad_(True)
+    loss = crit(xg, gt.cuda())
+    (loss * 2.0).backward()
+    assert abs(loss.item() - l64.item()) < 1e-3 * abs(l64.item())
+    assert rel_err(xg.grad.cpu() * 0.5, x64.grad) < 2e-3
