@@ -245,6 +245,64 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
 // Finalize of the above.  If mean != null (BatchNorm): writes dgamma, dbeta and the coefficients of
 //   dy = cA[c]*gz + cB[c]*y + cC[c]          (gz as defined above)
 // else (no BN: bias-only layer): writes dbias = sum gz.   dslope (scalar) += sum_c partial[2] when dslope != null.
+// Channel-parallel finalize: one workgroup per 64 channels (or ONE workgroup looping over all channels when the
+// scalar slope gradient is wanted, so that its sum over channels stays in one fixed-order reduction).
+// Thread (c = tid & 63, q = tid >> 6): 4 lanes per channel split the nblk partials (coalesced along c).
+__global__ __launch_bounds__(NT) void bwd_finalize2_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f) {
+  __shared__ float sm[3][NT];
+  __shared__ float red[NT / 64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  float al = 0.f;
+  const int cstep = gridDim.x * 64;
+  for (int cb = blockIdx.x * 64; cb < C; cb += cstep) {
+    const int c = cb + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+      for (int b = q; b < nblk; b += 4) {
+        const float* p = partial + (size_t)b * 3 * C + c;
+        s0 += p[0];
+        s1 += p[C];
+        s2 += p[2 * C];
+      }
+    }
+    __syncthreads();
+    sm[0][threadIdx.x] = s0;
+    sm[1][threadIdx.x] = s1;
+    sm[2][threadIdx.x] = s2;
+    __syncthreads();
+    if (q == 0 && c < C) {
+      s0 = sm[0][cl] + sm[0][cl + 64] + sm[0][cl + 128] + sm[0][cl + 192];
+      s1 = sm[1][cl] + sm[1][cl + 64] + sm[1][cl + 128] + sm[1][cl + 192];
+      s2 = sm[2][cl] + sm[2][cl + 64] + sm[2][cl + 128] + sm[2][cl + 192];
+      al += s2;
+      if (f.mean) {
+        const float mu = f.mean[c], rs = f.rstd[c], ga = f.gamma[c];
+        const float sgh = rs * (s1 - mu * s0);
+        const float m1 = s0 / f.n, m2 = sgh / f.n;
+        if (f.accumulate) {
+          f.dgamma[c] += sgh;
+          f.dbeta[c] += s0;
+        } else {
+          f.dgamma[c] = sgh;
+          f.dbeta[c] = s0;
+        }
+        const float a = ga * rs;
+        f.cA[c] = a;
+        f.cB[c] = -a * rs * m2;
+        f.cC[c] = -a * m1 + a * rs * mu * m2;
+      } else if (f.dbeta) {
+        if (f.accumulate) f.dbeta[c] += s0; else f.dbeta[c] = s0;
+      }
+    }
+  }
+  if (f.dslope) {                       // gridDim.x == 1 in this case (see the launcher)
+    al = block_sum<NT>(al, red);
+    if (threadIdx.x == 0) {
+      if (f.accumulate) f.dslope[0] += al; else f.dslope[0] = al;
+    }
+  }
+}
+
 constexpr int FT = 1024;   // threads of the stand-alone finalize kernel
 __global__ __launch_bounds__(FT) void bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f) {
   __shared__ float sm[3 * FT];
@@ -402,9 +460,10 @@ SST_API int sst_bwd_reduce_blocks_small(int64_t R, int C) {
 }
 
 SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
-  // few, fat blocks: the tensors are L2-resident and the finalize kernel walks the partials
-  int64_t nb = (R + 127) / 128;
-  if (nb > 256) nb = 256;
+  // ~8 float4 per thread, at most 128 workgroups (the finalize kernel walks nblk partials per channel)
+  int64_t nb = (R * (C / 4) + 256 * 8 - 1) / (256 * 8);
+  if (nb > 128) nb = 128;
+  if (nb > R) nb = R;
   return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -482,7 +541,7 @@ SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, con
   SST_REQUIRE(partial && nblk > 0 && C > 0, "sst_bwd_finalize: bad argument");
   SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize: BN mode needs all BN pointers");
   FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
-  bwd_finalize_kernel<<<1, FT, 0, sst_stream(stream)>>>(partial, nblk, C, fin);
+  bwd_finalize2_kernel<<<dslope ? 1 : (C + 63) / 64, NT, 0, sst_stream(stream)>>>(partial, nblk, C, fin);
   SST_LAUNCH_CHECK("bwd_finalize_kernel");
   return SST_OK;
 }

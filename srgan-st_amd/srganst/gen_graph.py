@@ -152,7 +152,7 @@ def backward(module, params, sv, dsr, need_dx=False):
         sl = p[pre + ".2.weight"]
         du = ops.bwd_reduce_apply(g, us, rows(us), slope=sl, act=1, dslope=grads[pre + ".2.weight"],
                                   unshuffle=True)                                    # [B,h,w,4C] pre-shuffle grad
-        ops.bwd_reduce_finalize(du, du, rows(du), dbeta=grads[pre + ".0.bias"])
+        ops.bwd_finalize(ops.bwd_reduce(du, du), rows(du), dbeta=grads[pre + ".0.bias"])
         with ops.SideStream(u_in, du, grads[pre + ".0.weight"]):
             ops.conv_wgrad(u_in, du, grads[pre + ".0.weight"], 3, 1, in_slope=slope_in,
                            in_act=ACT_SLOPE if slope_in is not None else 0)

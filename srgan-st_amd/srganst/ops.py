@@ -489,9 +489,17 @@ def conv9_to3_fwd(x, w, bias=None, in_slope=None, in_slope_const=0.0, in_act=ACT
 
 def bwd_reduce_apply(g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
                      gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False):
-    """Backward through [BatchNorm ->] activation in two launches: a few-workgroup reduction, then the apply kernel
-    whose workgroups derive the BN-backward coefficients from the raw partials themselves (workgroup 0 also writes
-    dgamma / dbeta / dslope).  Returns dy (pre-PixelShuffle layout when unshuffle)."""
+    """Backward through [BatchNorm ->] activation: row-parallel reduction, channel-parallel finalize (BN-backward
+    coefficients + dgamma / dbeta / dslope), elementwise apply.  Returns dy (pre-PixelShuffle layout when unshuffle)."""
+    part = bwd_reduce(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act)
+    cA, cB, cC = bwd_finalize(part, n, mean, rstd, gamma, dgamma, dbeta, dslope, accumulate)
+    return bwd_apply(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act, cA=cA, cB=cB, cC=cC,
+                     unshuffle=unshuffle)
+
+
+def _bwd_reduce_apply_fused(g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
+                            gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False):
+    """Two-launch variant (finalize folded into every apply workgroup); slower once C * nblk grows - kept for A/B."""
     C = y.shape[-1]
     R = y.numel() // C
     nblk = _abi.lib().sst_bwd_reduce_blocks_small(R, C)
