@@ -53,19 +53,29 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
   // 32 MFMAs run out of LDS (one register set, written to LDS after the barrier that retires the reads of t).
   f32x4 rx[4], rd[4];
   unsigned rvalid = 0;     // bit u: slot u holds an in-image pixel (padding must stay exactly zero)
+  // Per-slot pixel cursors (b, oy, ox) are kept incrementally: one 32-bit division per slot up front, then
+  // "advance by SUB pixels with carries" per sub-tile - the div/mod chains used to cost as many VALU cycles as
+  // the MFMAs of the sub-tile.
+  const int HW = a.Ho * a.Wo;
+  int sb[4], soy[4], sox[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned m = (unsigned)m_begin + ((tid + u * CONV_NT) >> 4);
+    sb[u] = (int)(m / (unsigned)HW);
+    const unsigned rem = m - (unsigned)sb[u] * HW;
+    soy[u] = (int)(rem / (unsigned)a.Wo);
+    sox[u] = (int)(rem - (unsigned)soy[u] * a.Wo);
+  }
+  const int adv_y = SUB / a.Wo, adv_x = SUB - adv_y * a.Wo;      // SUB pixels = adv_y rows + adv_x columns
+  const int c4 = (tid & 15) * 4;
   auto stage_load = [&](int64_t m0) {
     rvalid = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int q = tid + u * CONV_NT;
-      const int p = q >> 4, c4 = (q & 15) * 4;
-      const unsigned m = (unsigned)m0 + p;          // M < 2^31 (checked on the host): 32-bit index math
+      const int p = (tid + u * CONV_NT) >> 4;
       f32x4 xv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-      if (m < (unsigned)m_end) {
-        const unsigned hw = (unsigned)(a.Ho * a.Wo);
-        const int b = (int)(m / hw);
-        const unsigned rem = m - (unsigned)b * hw;
-        const int oy = (int)(rem / (unsigned)a.Wo), ox = (int)(rem - (unsigned)oy * a.Wo);
+      if ((int64_t)m0 + p < m_end) {
+        const int b = sb[u], oy = soy[u], ox = sox[u];
         const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
         const int c = ci0 + c4;
         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.Cin) {
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
         }
         const int co = co0 + c4;
         if (co < a.Cout) {
-          const float* src = a.dy + (size_t)m * a.Cout + co;
+          const float* src = a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
           if (dvec) {
             dv = *reinterpret_cast<const f32x4*>(src);
           } else {
@@ -93,6 +103,12 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
       }
       rx[u] = xv;
       rd[u] = dv;
+      // advance this slot's cursor by SUB pixels
+      int ox = sox[u] + adv_x, oy = soy[u] + adv_y;
+      if (ox >= a.Wo) { ox -= a.Wo; ++oy; }
+      if (oy >= a.Ho) { oy -= a.Ho; ++sb[u]; if (oy >= a.Ho) { sb[u] += oy / a.Ho; oy %= a.Ho; } }
+      sox[u] = ox;
+      soy[u] = oy;
     }
   };
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};   // a thread's channel quad is fixed (CONV_NT % 16 == 0)

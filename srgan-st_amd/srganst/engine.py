@@ -54,10 +54,19 @@ class _GraphedStep:
                     out = self.fn()
                 torch.cuda.current_stream().wait_stream(s)
                 return out
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.out = self.fn()
-            self.graph = g
+            try:
+                g = torch.cuda.CUDAGraph()
+                # thread_local: calls made by OTHER threads during capture (e.g. the RCCL watchdog polling its events)
+                # must not invalidate it
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.out = self.fn()
+                self.graph = g
+            except Exception as e:  # keep training (eager) rather than die: a step is still the same kernels
+                import sys
+                print(f"[srganst] hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode", file=sys.stderr)
+                torch.cuda.synchronize()
+                self.enabled = False
+                return self.fn()
         self.graph.replay()
         return self.out
 
