@@ -53,10 +53,11 @@ def bucket_slices(numels, buckets: int):
     return [s for s in out if s[0] < s[1]]
 
 
-def allreduce_grads(params, pg=None, buckets: int = 1) -> None:
-    """p.grad <- mean over ranks of p.grad, for every parameter that has a gradient."""
+def allreduce_grads(params, pg=None, buckets: int = 1, force: bool = False) -> None:
+    """p.grad <- mean over ranks of p.grad, for every parameter that has a gradient.
+    force: issue the collective even with a single rank (exercises the RCCL path in tests)."""
     world = world_size(pg)
-    if world == 1:
+    if world == 1 and not (force and td.is_available() and td.is_initialized()):
         return
     ps = [p for p in params if p.grad is not None]
     if not ps:

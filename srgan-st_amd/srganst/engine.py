@@ -75,7 +75,7 @@ class WarmupEngine:
     """reference warmup.py:14-96 without the data loader / logging / validation around the step."""
 
     def __init__(self, config, generator, criterions=None, weights=None, use_graph=None, process_group=None,
-                 adam_capturable=None):
+                 adam_capturable=None, force_dp=False):
         self.config = config
         self.G = generator
         self.criterions = criterions if criterions is not None else config.MODEL.G_LOSS.WARMUP_CRITERIONS
@@ -89,7 +89,8 @@ class WarmupEngine:
         self.gt = self.lr = None
         self.loss_values = OrderedDict()
         self.sr = None
-        if self.world > 1:      # collective stays outside the graph: [fwd+bwd graph] -> all-reduce -> [optimizer]
+        self.dp = self.world > 1 or force_dp     # force_dp: run the split-graph + collective path even with one rank (tests)
+        if self.dp:             # collective stays outside the graph: [fwd+bwd graph] -> all-reduce -> [optimizer]
             self._fb = _GraphedStep(self._fwd_bwd, enabled=use_graph)
             self._op = _GraphedStep(self._opt_step, enabled=use_graph)
         else:
@@ -127,8 +128,8 @@ class WarmupEngine:
             self.gt.copy_(gt, non_blocking=True)
             self.lr.copy_(lr, non_blocking=True)
         self._fb()
-        if self.world > 1:
-            sdist.allreduce_grads(self.G.parameters(), self.pg)
+        if self.dp:
+            sdist.allreduce_grads(self.G.parameters(), self.pg, force=True)
             self._op()
         return self.loss_values
 

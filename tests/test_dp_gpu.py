@@ -104,3 +104,43 @@ def test_dp_world2_matches_mean_gradient_step(use_graph):
     for k, v in G1.state_dict().items():
         if "running" in k:
             assert torch.allclose(v.cpu(), res[1][k], rtol=1e-5, atol=1e-7), k
+
+
+def _nccl_worker(port, q):
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "srgan-st_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as td
+    from srganst.engine import WarmupEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    torch.cuda.set_device(0)
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))    # RCCL communicator + watchdog thread
+    out = []
+    for force_dp in (False, True):
+        cfg, G = _make(seed=5)
+        eng = WarmupEngine(cfg, G, {"Pixel": MSELoss(), "ST": StructureTensorLoss()}, {"Pixel": 1.0, "ST": 1 / 3},
+                           use_graph=True, adam_capturable=True, force_dp=force_dp)
+        for step in range(5):
+            eng.step(*_batch(0, step))
+        torch.cuda.synchronize()
+        assert eng._fb.graph is not None, "hipGraph capture fell back to eager next to a live RCCL communicator"
+        out.append({k: v.cpu().numpy() for k, v in G.state_dict().items()})
+    q.put(out)
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_graph_capture_next_to_rccl_communicator():
+    """RCCL (backend nccl) initialised, its watchdog thread alive: hipGraph capture must still work, and the split
+    [fwd+bwd graph] -> all-reduce over RCCL -> [optimizer graph] path must equal the single-graph path."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    a, b = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for k in a:
+        assert (a[k] == b[k]).all(), k
