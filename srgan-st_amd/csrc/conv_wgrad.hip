@@ -10,6 +10,7 @@
 // Each workgroup writes its partial 64x64 tile to a slab [chunk][tap][Cout][Cin]; wgrad_reduce sums the
 // chunks in fixed order into the reference layout [Cout][Cin][KS][KS]  (no atomics: reproducible).
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -27,6 +28,7 @@ struct WgradArgs {
   int in_act;
   int B, H, W, Cin, Cout, Ho, Wo, stride, KS, pad;
   int chunk_px;            // pixels per chunk (multiple of SUB)
+  int dbg;                 // dev ablation bits from $SST_WGRAD_DBG (0 in production): 1 no global loads, 2 no MFMA, 4 no slab store
 };
 
 __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
     for (int u = 0; u < 4; ++u) {
       const int p = (tid + u * CONV_NT) >> 4;
       f32x4 xv = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-      if ((int64_t)m0 + p < m_end) {
+      if ((int64_t)m0 + p < m_end && !(a.dbg & 1)) {
         const int b = sb[u], oy = soy[u], ox = sox[u];
         const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
         const int c = ci0 + c4;
@@ -157,13 +159,17 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
     if (m0 + SUB < m_end) stage_load(m0 + SUB);
     // ---- 32 MFMAs: K = 64 pixels, 2 per instruction (lane half lh picks the pixel of the pair)
 #pragma unroll 8
-    for (int kk = 0; kk < SUB / 2; ++kk) {
+    for (int kk = 0; kk < ((a.dbg & 2) ? 0 : SUB / 2); ++kk) {
       const float av = sD[(2 * kk + lh) * WLD + wco + li];
       const float bv = sX[(2 * kk + lh) * WLD + wci + li];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
   }
   // ---- store the partial tile: rows = co, cols = ci (lanes contiguous along ci)
+  if (a.dbg & 4) {
+    if (acc[0] == 12345.f) a.slab[0] = 1.f;
+    return;
+  }
   float* out = a.slab + ((size_t)blockIdx.x * gridDim.y + tap) * a.Cout * a.Cin;
   const int ci = ci0 + wci + li;
 #pragma unroll
@@ -211,8 +217,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 SST_API int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int ksize) {
   const int64_t M = (int64_t)B * Ho * Wo;
   const int nblk = ((Cout + 63) / 64) * ((Cin + 63) / 64);
-  int64_t want = (320 + ksize * ksize * nblk - 1) / (ksize * ksize * nblk);   // ~1.2 workgroups per CU: keeps the slabs small
-  int64_t maxc = (M + SUB - 1) / SUB;
+  // Measured on MI355X (tools/ablate_wgrad.py): ~4 co-resident workgroups per CU hide the staging latency best, as long
+  // as a workgroup still gets >= ~160 pixels of K (shorter chunks are all fixed cost + slab traffic).
+  int64_t want = (1024 + ksize * ksize * nblk - 1) / (ksize * ksize * nblk);
+  int64_t maxc = (M + 159) / 160;
   if (want > maxc) want = maxc;
   if (want < 1) want = 1;
   int64_t chunk_px = ((M + want - 1) / want + SUB - 1) / SUB * SUB;
@@ -235,6 +243,10 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   SST_REQUIRE(M < (1ll << 31), "sst_conv_wgrad: too many pixels");
   const int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
   a.chunk_px = (int)(((M + nchunk - 1) / nchunk + SUB - 1) / SUB * SUB);
+  {
+    const char* e = getenv("SST_WGRAD_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   const int KK = ksize * ksize;
   dim3 grid(nchunk, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
   conv_wgrad_kernel<<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
