@@ -245,12 +245,13 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
 // Finalize of the above.  If mean != null (BatchNorm): writes dgamma, dbeta and the coefficients of
 //   dy = cA[c]*gz + cB[c]*y + cC[c]          (gz as defined above)
 // else (no BN: bias-only layer): writes dbias = sum gz.   dslope (scalar) += sum_c partial[2] when dslope != null.
-// Channel-parallel finalize: one workgroup per 64 channels (or ONE workgroup looping over all channels when the
-// scalar slope gradient is wanted, so that its sum over channels stays in one fixed-order reduction).
-// Thread (c = tid & 63, q = tid >> 6): 4 lanes per channel split the nblk partials (coalesced along c).
-__global__ __launch_bounds__(NT) void bwd_finalize2_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f) {
-  __shared__ float sm[3][NT];
-  __shared__ float red[NT / 64];
+// Channel-parallel finalize: one workgroup of 1024 threads per 64 channels (or ONE workgroup looping over all channels
+// when the scalar slope gradient is wanted, so that its sum over channels stays in one fixed-order reduction).
+// Thread (c = tid & 63, q = tid >> 6): 16 lanes per channel split the nblk partials (coalesced along c, 4-5 loads deep).
+constexpr int F2T = 1024;
+__global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f) {
+  __shared__ float sm[3][F2T];
+  __shared__ float red[F2T / 64];
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
   float al = 0.f;
   const int cstep = gridDim.x * 64;
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(NT) void bwd_finalize2_kernel(const float* __restri
     const int c = cb + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if (c < C) {
-      for (int b = q; b < nblk; b += 4) {
+#pragma unroll 4
+      for (int b = q; b < nblk; b += F2T / 64) {
         const float* p = partial + (size_t)b * 3 * C + c;
         s0 += p[0];
         s1 += p[C];
@@ -271,9 +273,13 @@ __global__ __launch_bounds__(NT) void bwd_finalize2_kernel(const float* __restri
     sm[2][threadIdx.x] = s2;
     __syncthreads();
     if (q == 0 && c < C) {
-      s0 = sm[0][cl] + sm[0][cl + 64] + sm[0][cl + 128] + sm[0][cl + 192];
-      s1 = sm[1][cl] + sm[1][cl + 64] + sm[1][cl + 128] + sm[1][cl + 192];
-      s2 = sm[2][cl] + sm[2][cl + 64] + sm[2][cl + 128] + sm[2][cl + 192];
+      s0 = s1 = s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < F2T / 64; ++i) {
+        s0 += sm[0][cl + 64 * i];
+        s1 += sm[1][cl + 64 * i];
+        s2 += sm[2][cl + 64 * i];
+      }
       al += s2;
       if (f.mean) {
         const float mu = f.mean[c], rs = f.rstd[c], ga = f.gamma[c];
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(NT) void bwd_finalize2_kernel(const float* __restri
     }
   }
   if (f.dslope) {                       // gridDim.x == 1 in this case (see the launcher)
-    al = block_sum<NT>(al, red);
+    al = block_sum<F2T>(al, red);
     if (threadIdx.x == 0) {
       if (f.accumulate) f.dslope[0] += al; else f.dslope[0] = al;
     }
@@ -541,7 +547,7 @@ SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, con
   SST_REQUIRE(partial && nblk > 0 && C > 0, "sst_bwd_finalize: bad argument");
   SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize: BN mode needs all BN pointers");
   FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
-  bwd_finalize2_kernel<<<dslope ? 1 : (C + 63) / 64, NT, 0, sst_stream(stream)>>>(partial, nblk, C, fin);
+  bwd_finalize2_kernel<<<dslope ? 1 : (C + 63) / 64, F2T, 0, sst_stream(stream)>>>(partial, nblk, C, fin);
   SST_LAUNCH_CHECK("bwd_finalize_kernel");
   return SST_OK;
 }
