@@ -54,6 +54,13 @@ int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const 
                  float in_slope_const, int in_act, const float* residual, float* stats,
                  float* stats_cnt, int out_mode, int B, int H, int W, int Cin, int Cout, int ksize,
                  int stride, void* stream);
+/* stride-1 data-gradient (mode 1 weights) whose epilogue also emits the BatchNorm/activation BACKWARD partial sums of
+ * its result g against the saved conv output epi_y: epi_partial [sst_conv_mtiles][3][Cout] = per-tile sums of
+ * (gz, gz*epi_y, g*min(z,0)) - the layout sst_bwd_finalize consumes (replaces a separate sst_bwd_reduce pass). */
+int sst_conv_dgrad_bwdstats(const float* x, const float* wp, float* y, const float* residual, const float* epi_y,
+                            const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                            float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
+                            int Cout, int ksize, void* stream);
 /* dW[Cout][Cin][k][k] (+)= sum_pixels X'(shifted) * dY ; slab = sst_conv_wgrad_chunks*k*k*Cout*Cin floats */
 int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int ksize);
 int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,

@@ -38,6 +38,11 @@ struct Conv3Args {
   float* stats;            // [n_mtiles][2][Cout] (sum, M2) or null
   float* stats_cnt;        // [n_mtiles] valid pixels per tile (written when stats != null)
   float* y_pre;            // OUT_NCHW_CLAMP: pre-clamp copy (saved for backward) or null
+  // optional BatchNorm/activation BACKWARD partials of the stored value g (this conv is then a data-gradient):
+  //   with z = epi_y*epi_scale+epi_shift (or epi_y), gz = epi_act ? (z>0 ? g : g*slope) : g
+  //   epi_partial[mtile][0..2][c] = sum over the tile's pixels of (gz, gz*epi_y, g*min(z,0))   (layout of bwd_reduce)
+  const float* epi_y; const float* epi_scale; const float* epi_shift; const float* epi_slope;
+  float epi_slope_const; int epi_act; float* epi_partial;
   int out_mode;            // OUT_*
   int ksy, ksx, pad_y, pad_x;   // runtime tap window (<= KS x KS) and padding: KS,KS,KS/2,KS/2 for a plain conv
   int sub_y, sub_x;        // OUT_STRIDE2: parity class of the scattered output pixels
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
   constexpr int PW = (TWO - 1) * S + KS, PH = (THO - 1) * S + KS, NP = PW * PH;
   constexpr int LDS_FLOATS = (NP * LDSC > 4 * 32 * 33) ? NP * LDSC : 4 * 32 * 33;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  __shared__ float sstat[4][2][32];
+  __shared__ float sstat[4][3][32];
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
   const int tiles_x = (a.Wo + TWO - 1) / TWO, tiles_y = (a.Ho + THO - 1) / THO;
@@ -313,6 +318,53 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
       if (tid == 0 && nf == 0) a.stats_cnt[mt] = (float)nvalid;
     }
   }
+  if (a.epi_partial) {
+    // backward partials for the BatchNorm / activation that produced this conv's consumer-side input (see Conv3Args)
+    const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
+    float q[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g = 0.f, yv = 0.f, z = 0.f;
+      if (pix_ok && n0 + j < a.Cout) {
+        g = v[j];
+        yv = a.epi_y[obase + j];
+        z = a.epi_scale ? fmaf(yv, a.epi_scale[n0 + j], a.epi_shift[n0 + j]) : yv;
+      }
+      float gz = g;
+      float q2 = 0.f;
+      if (a.epi_act) {
+        q2 = g * fminf(z, 0.f);
+        gz = z > 0.f ? g : g * eslope;
+      }
+      q[0][j] = gz;
+      q[1][j] = gz * yv;
+      q[2][j] = q2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = q[k][j];
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        q[k][j] = t;
+      }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sstat[wave][k][lane * 4 + j] = q[k][j];
+    }
+    __syncthreads();
+    if (tid < 96) {
+      const int k = tid >> 5, c = tid & 31;
+      if (nf * 32 + c < a.Cout)
+        a.epi_partial[((size_t)mt * 3 + k) * a.Cout + nf * 32 + c] =
+            sstat[0][k][c] + sstat[1][k][c] + sstat[2][k][c] + sstat[3][k][c];
+    }
+  }
 }
 
 // w [Cout][Cin][3][3] (reference layout) -> packed.  mode 0: forward.  mode 1: data-gradient of a stride-1
@@ -446,10 +498,11 @@ SST_API int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, v
 SST_API int sst_conv_mtiles(int B, int Ho, int Wo) { return B * ((Ho + THO - 1) / THO) * ((Wo + TWO - 1) / TWO); }
 
 // y = conv(act(x*in_scale+in_shift), w) (+bias) (+residual), stored per out_mode; optional BN partial stats.
-SST_API int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias, const float* in_scale,
+static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre, const float* bias, const float* in_scale,
                          const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
                          const float* residual, float* stats, float* stats_cnt, int out_mode, int B, int H, int W, int Cin,
-                         int Cout, int ksize, int stride, void* stream) {
+                         int Cout, int ksize, int stride, const float* epi_y, const float* epi_scale, const float* epi_shift,
+                         const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, void* stream) {
   SST_REQUIRE(x && wp && y, "sst_conv_fwd: null pointer");
   SST_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 9),
               "sst_conv_fwd: bad shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d stride=%d", B, H, W, Cin, Cout, ksize, stride);
@@ -460,11 +513,15 @@ SST_API int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre
   out_mode &= 0xff;
   SST_REQUIRE(out_mode >= 0 && out_mode <= 3, "sst_conv_fwd: bad out_mode");
   SST_REQUIRE(out_mode != OUT_SHUFFLE || (Cout & 3) == 0, "sst_conv_fwd: shuffle store needs Cout %% 4 == 0");
-  SST_REQUIRE(out_mode == OUT_NHWC || (!residual && !stats), "sst_conv_fwd: residual/stats only with NHWC store");
+  SST_REQUIRE(out_mode == OUT_NHWC || (!residual && !stats && !epi_partial), "sst_conv_fwd: residual/stats only with NHWC store");
+  SST_REQUIRE(!epi_partial || (epi_y && !stats && ((epi_scale == nullptr) == (epi_shift == nullptr))),
+              "sst_conv_fwd: backward partials need epi_y and exclude forward stats");
   Conv3Args a;
   a.x = x; a.wp = wp; a.y = y; a.y_pre = y_pre; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift;
   a.in_slope = in_slope; a.in_slope_const = in_slope_const; a.in_act = in_act; a.residual = residual; a.stats = stats;
   a.stats_cnt = stats_cnt; a.out_mode = out_mode; a.dbg = dbg_bits;
+  a.epi_y = epi_y; a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_slope = epi_slope;
+  a.epi_slope_const = epi_slope_const; a.epi_act = epi_act; a.epi_partial = epi_partial;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.ksy = a.ksx = ksize; a.pad_y = a.pad_x = ksize / 2; a.sub_y = a.sub_x = 0; a.Hy = a.Wy = 0;
   a.Ho = (H + 2 * (ksize / 2) - ksize) / stride + 1;
@@ -484,6 +541,26 @@ SST_API int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre
     conv_fwd_kernel<9, 1><<<grid, CONV_NT, 0, st>>>(a);
   SST_LAUNCH_CHECK("conv_fwd_kernel");
   return SST_OK;
+}
+
+SST_API int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias, const float* in_scale,
+                         const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
+                         const float* residual, float* stats, float* stats_cnt, int out_mode, int B, int H, int W, int Cin,
+                         int Cout, int ksize, int stride, void* stream) {
+  return conv_fwd_impl(x, wp, y, y_pre, bias, in_scale, in_shift, in_slope, in_slope_const, in_act, residual, stats, stats_cnt,
+                       out_mode, B, H, W, Cin, Cout, ksize, stride, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, stream);
+}
+
+// Data-gradient conv (NHWC store, optional residual) that also emits the BatchNorm/activation backward partials of its
+// result g against the saved conv output epi_y:  epi_partial [sst_conv_mtiles][3][Cout]  (same layout as sst_bwd_reduce).
+SST_API int sst_conv_dgrad_bwdstats(const float* x, const float* wp, float* y, const float* residual, const float* epi_y,
+                                    const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                                    float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
+                                    int Cout, int ksize, void* stream) {
+  SST_REQUIRE(epi_y && epi_partial, "sst_conv_dgrad_bwdstats: epi_y / epi_partial");
+  return conv_fwd_impl(x, wp, y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, ACT_NONE, residual, nullptr, nullptr, OUT_NHWC,
+                       B, H, W, Cin, Cout, ksize, 1, epi_y, epi_scale, epi_shift, epi_slope, epi_slope_const, epi_act, epi_partial,
+                       stream);
 }
 
 // ---- data-gradient of a 3x3 stride-2 pad-1 convolution (Discriminator.features, model.py:35,42,49,56)
@@ -509,6 +586,7 @@ SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B
     a.x = dy; a.wp = wp + s2_class_offset(cls, Cin, Cout); a.y = dx; a.y_pre = nullptr; a.bias = nullptr;
     a.in_scale = a.in_shift = a.in_slope = nullptr; a.in_slope_const = 0.f; a.in_act = ACT_NONE;
     a.residual = nullptr; a.stats = nullptr; a.stats_cnt = nullptr; a.out_mode = OUT_STRIDE2; a.dbg = 0;
+    a.epi_y = a.epi_scale = a.epi_shift = a.epi_slope = nullptr; a.epi_slope_const = 0.f; a.epi_act = 0; a.epi_partial = nullptr;
     a.B = B; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin;     // roles swap: the "input" of this conv is dy
     a.ksy = 1 + py; a.ksx = 1 + px; a.pad_y = a.pad_x = 0; a.sub_y = py; a.sub_x = px;
     a.Ho = nh; a.Wo = nw; a.Hy = H; a.Wy = W;

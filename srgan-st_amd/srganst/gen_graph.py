@@ -166,25 +166,35 @@ def backward(module, params, sv, dsr, need_dx=False):
         ops.conv_wgrad(sv["h_last"], dy3, grads["conv2.0.weight"], 3, 1,
                        in_slope=a1 if not sv["blocks"] else None, in_act=ACT_SLOPE if not sv["blocks"] else 0)
     dskip = g
-    dh = ops.conv_fwd(dy3, wd["conv2.0.weight"], C, 3, 1)[0]
+    nb = len(sv["blocks"])
+    # every stride-1 data-gradient conv below also emits the BatchNorm-backward partial sums of its result against the
+    # conv output the NEXT backward stage differentiates through (saves one reduction pass per stage)
+    if nb:
+        dh, part = ops.conv_dgrad_bwdstats(dy3, wd["conv2.0.weight"], C, 3, sv["blocks"][-1][6])        # vs y2 of the last block
+    else:
+        dh, part = ops.conv_fwd(dy3, wd["conv2.0.weight"], C, 3, 1)[0], None
     # ---- residual blocks, last to first
-    for i in reversed(range(len(sv["blocks"]))):
+    for i in reversed(range(nb)):
         pre = f"trunk.{i}.rcb"
         first = i == 0
         h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2 = sv["blocks"][i]
         sl = p[pre + ".2.weight"]
-        dy2 = ops.bwd_reduce_apply(dh, y2, n, scale=s2, shift=t2, mean=m2, rstd=r2, gamma=p[pre + ".4.weight"],
-                                   dgamma=grads[pre + ".4.weight"], dbeta=grads[pre + ".4.bias"])
+        dy2 = ops.bwd_finalize_apply(part, dh, y2, n, scale=s2, shift=t2, mean=m2, rstd=r2, gamma=p[pre + ".4.weight"],
+                                     dgamma=grads[pre + ".4.weight"], dbeta=grads[pre + ".4.bias"])
         with ops.SideStream(y1, dy2, grads[pre + ".3.weight"]):
             ops.conv_wgrad(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
-        dp1 = ops.conv_fwd(dy2, wd[pre + ".3.weight"], C, 3, 1)[0]
-        dy1 = ops.bwd_reduce_apply(dp1, y1, n, scale=s1, shift=t1, slope=sl, act=1, mean=m1, rstd=r1,
-                                   gamma=p[pre + ".1.weight"], dgamma=grads[pre + ".1.weight"],
-                                   dbeta=grads[pre + ".1.bias"], dslope=grads[pre + ".2.weight"])
+        dp1, part = ops.conv_dgrad_bwdstats(dy2, wd[pre + ".3.weight"], C, 3, y1, epi_scale=s1, epi_shift=t1, epi_slope=sl,
+                                            epi_act=1)
+        dy1 = ops.bwd_finalize_apply(part, dp1, y1, n, scale=s1, shift=t1, slope=sl, act=1, mean=m1, rstd=r1,
+                                     gamma=p[pre + ".1.weight"], dgamma=grads[pre + ".1.weight"],
+                                     dbeta=grads[pre + ".1.bias"], dslope=grads[pre + ".2.weight"])
         with ops.SideStream(h, dy1, grads[pre + ".0.weight"]):
             ops.conv_wgrad(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None,
                            in_act=ACT_SLOPE if first else 0)
-        dh = ops.conv_fwd(dy1, wd[pre + ".0.weight"], C, 3, 1, residual=dh)[0]
+        if first:
+            dh = ops.conv_fwd(dy1, wd[pre + ".0.weight"], C, 3, 1, residual=dh)[0]
+        else:
+            dh, part = ops.conv_dgrad_bwdstats(dy1, wd[pre + ".0.weight"], C, 3, sv["blocks"][i - 1][6], residual=dh)
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
     dz1 = ops.bwd_reduce_apply(dh, z1, n, g2=dskip, slope=a1, act=1, dbeta=grads["conv1.0.bias"],

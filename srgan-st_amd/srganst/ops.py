@@ -542,3 +542,30 @@ def maxpool_relu_bwd(g, y):
     dy = torch.empty_like(y)
     check(_abi.lib().sst_maxpool_relu_bwd(ptr(g), ptr(y), ptr(dy), B, H, W, C, stream_ptr()), "sst_maxpool_relu_bwd")
     return dy
+
+
+def conv_dgrad_bwdstats(dy, wd, cout, ksize, epi_y, residual=None, epi_scale=None, epi_shift=None, epi_slope=None,
+                        epi_slope_const=0.0, epi_act=0):
+    """Stride-1 data-gradient g = conv(dy, wd) (+ residual) that also returns the BN/activation backward partials of g
+    against epi_y ([mtiles,3,cout], the layout bwd_finalize consumes)."""
+    B, H, W, cin = dy.shape
+    g = _f32(B, H, W, cout, like=dy)
+    mt = _abi.lib().sst_conv_mtiles(B, H, W)
+    partial = _f32(mt, 3, cout, like=dy)
+    args = (ptr(dy), ptr(wd), ptr(g), ptr(residual), ptr(epi_y), ptr(epi_scale), ptr(epi_shift), ptr(epi_slope),
+            float(epi_slope_const), int(epi_act), ptr(partial), B, H, W, cin, cout, ksize)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv_dgrad_bwdstats(*args, stream_ptr()), "sst_conv_dgrad_bwdstats")
+    flops = 2.0 * B * H * W * cout * cin * ksize * ksize
+    _prof_end(e0, f"conv_fwd_kernel<{ksize},1>", flops)
+    _trace(f"conv_fwd_kernel<{ksize},1>", flops, lambda: _abi.lib().sst_conv_dgrad_bwdstats(*args, stream_ptr()),
+           dy, wd, g, residual, epi_y, epi_scale, epi_shift, epi_slope, partial)
+    return g, partial
+
+
+def bwd_finalize_apply(part, g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
+                       gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False):
+    """bwd_reduce_apply with the reduction already done (partials from conv_dgrad_bwdstats)."""
+    cA, cB, cC = bwd_finalize(part, n, mean, rstd, gamma, dgamma, dbeta, dslope, accumulate)
+    return bwd_apply(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act, cA=cA, cB=cB, cC=cC,
+                     unshuffle=unshuffle)
