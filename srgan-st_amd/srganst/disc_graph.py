@@ -79,6 +79,7 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
     g = ops.linear_dgrad(dh1, p["classifier.0.weight"], nhwc=(C, H * W)).view(B, H, W, C)   # d LReLU(BN(y_last)) in NHWC
     dx = None
     wd = _packs(module, p, 1)
+    part = None                      # BN/activation backward partials of g, when the producing dgrad conv emitted them
     for li in reversed(range(len(sv["layers"]))):
         r = sv["layers"][li]
         y = r["y"]
@@ -89,12 +90,15 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
             gam = p[f"features.{bi}.weight"]
             dg = G(f"features.{bi}.weight") if wg else torch.empty_like(gam)
             db = G(f"features.{bi}.bias") if wg else torch.empty_like(gam)
-            dy = ops.bwd_reduce_apply(g, y, n, scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1,
-                                      mean=r["mean"], rstd=r["rstd"], gamma=gam, dgamma=dg, dbeta=db)
+            kw = dict(scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1, mean=r["mean"], rstd=r["rstd"], gamma=gam,
+                      dgamma=dg, dbeta=db)
+            dy = ops.bwd_finalize_apply(part, g, y, n, **kw) if part is not None else ops.bwd_reduce_apply(g, y, n, **kw)
         elif wg:
-            dy = ops.bwd_reduce_apply(g, y, n, slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"))
+            kw = dict(slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"))
+            dy = ops.bwd_finalize_apply(part, g, y, n, **kw) if part is not None else ops.bwd_reduce_apply(g, y, n, **kw)
         else:
             dy = ops.bwd_apply(g, y, slope_const=LRELU, act=1)
+        part = None
         if wg:
             dwc = G(f"features.{ci}.weight")
             with ops.SideStream(r["x"], dy, dwc):
@@ -104,7 +108,13 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
             break
         xin = r["x"]
         if r["stride"] == 1:
-            g = ops.conv_fwd(dy, wd[f"features.{ci}.weight"], w.shape[1], 3, 1)[0]
+            if li > 0:               # g differentiates through the previous layer's BN + LeakyReLU: emit its partials here
+                prev = sv["layers"][li - 1]
+                g, part = ops.conv_dgrad_bwdstats(dy, wd[f"features.{ci}.weight"], w.shape[1], 3, prev["y"],
+                                                  epi_scale=prev["scale"], epi_shift=prev["shift"], epi_slope_const=LRELU,
+                                                  epi_act=1)
+            else:
+                g = ops.conv_fwd(dy, wd[f"features.{ci}.weight"], w.shape[1], 3, 1)[0]
         else:
             g = ops.conv_s2_dgrad(dy, ops.pack_conv_s2_dgrad(w), xin.shape[1], xin.shape[2], w.shape[1])
         if li == 0:
