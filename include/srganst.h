@@ -61,6 +61,14 @@ int sst_conv_dgrad_bwdstats(const float* x, const float* wp, float* y, const flo
                             const float* epi_scale, const float* epi_shift, const float* epi_slope,
                             float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
                             int Cout, int ksize, void* stream);
+/* one launch per BatchNorm-backward stage: BN+activation backward apply on load (dy = cA*gz + cB*y2 + cC, also written
+ * to dy_out for the weight-gradient kernel), data-gradient conv (+ residual), optional partials for the next stage. */
+int sst_conv_dgrad_fused(const float* g, const float* y2, const float* cA, const float* cB, const float* cC,
+                         const float* in_scale, const float* in_shift, const float* in_slope, float in_slope_const,
+                         int in_act, float* dy_out, const float* wp, float* out, const float* residual,
+                         const float* epi_y, const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                         float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin, int Cout,
+                         int ksize, void* stream);
 /* dW[Cout][Cin][k][k] (+)= sum_pixels X'(shifted) * dY ; slab = sst_conv_wgrad_chunks*k*k*Cout*Cin floats */
 int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int ksize);
 int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,

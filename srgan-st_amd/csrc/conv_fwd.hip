@@ -38,6 +38,10 @@ struct Conv3Args {
   float* stats;            // [n_mtiles][2][Cout] (sum, M2) or null
   float* stats_cnt;        // [n_mtiles] valid pixels per tile (written when stats != null)
   float* y_pre;            // OUT_NCHW_CLAMP: pre-clamp copy (saved for backward) or null
+  // optional fused BatchNorm-backward APPLY on the input (this conv is then the data-gradient of the layer below):
+  //   the staged value is dy = cA*gz + cB*y2 + cC with gz = in_act ? (y2*in_scale+in_shift > 0 ? x : x*slope) : x,
+  //   x = upstream gradient, in2 = saved conv output y2 [B,H,W,Cin]; dy of the tile's own pixels goes to side_out.
+  const float* in2; const float* in_cA; const float* in_cB; const float* in_cC; float* side_out;
   // optional BatchNorm/activation BACKWARD partials of the stored value g (this conv is then a data-gradient):
   //   with z = epi_y*epi_scale+epi_shift (or epi_y), gz = epi_act ? (z>0 ? g : g*slope) : g
   //   epi_partial[mtile][0..2][c] = sum over the tile's pixels of (gz, gz*epi_y, g*min(z,0))   (layout of bwd_reduce)
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
     {
       const int c4 = (tid & 15) * 4, c = c0 + c4;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      f32x4 kA = {1.f, 1.f, 1.f, 1.f}, kB = {0.f, 0.f, 0.f, 0.f}, kC = {0.f, 0.f, 0.f, 0.f};
       if (a.in_scale) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -149,12 +154,22 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
             sh[j] = a.in_shift[c + j];
           }
       }
+      if (a.in_cA) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < a.Cin) {
+            kA[j] = a.in_cA[c + j];
+            kB[j] = a.in_cB[c + j];
+            kC[j] = a.in_cC[c + j];
+          }
+      }
       for (int p = tid >> 4; p < ((a.dbg & 1) ? 0 : NP); p += CONV_NT / 16) {
         const int py = p / PW, px = p - py * PW;
         const int iy = iy0 + py, ix = ix0 + px;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.Cin) {
-          const float* src = a.x + (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + c;
+          const size_t off = (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + c;
+          const float* src = a.x + off;
           if (vec_ok) {
             v = *reinterpret_cast<const f32x4*>(src);
           } else {
@@ -162,13 +177,29 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
             for (int j = 0; j < 4; ++j)
               if (c + j < a.Cin) v[j] = src[j];
           }
-          if (a.in_scale) {
+          if (a.in2) {                       // fused BN-backward apply (vec_ok is required by the host wrapper)
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(a.in2 + off);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
-          }
-          if (a.in_act == ACT_SLOPE) {
+            for (int j = 0; j < 4; ++j) {
+              float gz = v[j];
+              if (a.in_act == ACT_SLOPE) {
+                const float z = fmaf(yv[j], sc[j], sh[j]);
+                gz = z > 0.f ? gz : gz * slope;
+              }
+              v[j] = a.in_cA ? fmaf(kA[j], gz, fmaf(kB[j], yv[j], kC[j])) : gz;
+            }
+            // the tile's own pixels (S == 1: patch interior) are written once, by the nf == 0 workgroup
+            if (a.side_out && nf == 0 && py >= a.pad_y && py < a.pad_y + THO && px >= a.pad_x && px < a.pad_x + TWO)
+              *reinterpret_cast<f32x4*>(a.side_out + off) = v;
+          } else {
+            if (a.in_scale) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+              for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+            }
+            if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+            }
           }
           if (!vec_ok) {
 #pragma unroll
@@ -502,7 +533,9 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
                          const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
                          const float* residual, float* stats, float* stats_cnt, int out_mode, int B, int H, int W, int Cin,
                          int Cout, int ksize, int stride, const float* epi_y, const float* epi_scale, const float* epi_shift,
-                         const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, void* stream) {
+                         const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, void* stream,
+                         const float* in2 = nullptr, const float* in_cA = nullptr, const float* in_cB = nullptr,
+                         const float* in_cC = nullptr, float* side_out = nullptr) {
   SST_REQUIRE(x && wp && y, "sst_conv_fwd: null pointer");
   SST_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 9),
               "sst_conv_fwd: bad shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d stride=%d", B, H, W, Cin, Cout, ksize, stride);
@@ -522,6 +555,9 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   a.stats_cnt = stats_cnt; a.out_mode = out_mode; a.dbg = dbg_bits;
   a.epi_y = epi_y; a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_slope = epi_slope;
   a.epi_slope_const = epi_slope_const; a.epi_act = epi_act; a.epi_partial = epi_partial;
+  a.in2 = in2; a.in_cA = in_cA; a.in_cB = in_cB; a.in_cC = in_cC; a.side_out = side_out;
+  SST_REQUIRE(!in2 || ((Cin & 3) == 0 && stride == 1), "sst_conv_fwd: fused BN-backward input needs Cin %% 4 == 0, stride 1");
+  SST_REQUIRE(!in_cA || (in2 && in_cB && in_cC), "sst_conv_fwd: cA/cB/cC need in2");
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.ksy = a.ksx = ksize; a.pad_y = a.pad_x = ksize / 2; a.sub_y = a.sub_x = 0; a.Hy = a.Wy = 0;
   a.Ho = (H + 2 * (ksize / 2) - ksize) / stride + 1;
@@ -563,6 +599,25 @@ SST_API int sst_conv_dgrad_bwdstats(const float* x, const float* wp, float* y, c
                        stream);
 }
 
+// The whole BatchNorm-backward stage of a stride-1 conv in one launch:
+//   dy   = cA*gz + cB*y2 + cC, gz = in_act ? (y2*in_scale+in_shift > 0 ? g : g*slope) : g     (BN+activation backward apply,
+//                                                                           computed while the input tile is staged)
+//   dy_out[b,y,x,:] = dy                                                     (side output for the weight-gradient kernel)
+//   out  = conv(dy, wp) (+ residual)                                         (data-gradient, mode-1 weights)
+//   epi_partial = BN/activation backward partials of `out` against epi_y     (optional, as sst_conv_dgrad_bwdstats)
+SST_API int sst_conv_dgrad_fused(const float* g, const float* y2, const float* cA, const float* cB, const float* cC,
+                                 const float* in_scale, const float* in_shift, const float* in_slope, float in_slope_const,
+                                 int in_act, float* dy_out, const float* wp, float* out, const float* residual,
+                                 const float* epi_y, const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                                 float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin, int Cout,
+                                 int ksize, void* stream) {
+  SST_REQUIRE(g && y2 && dy_out, "sst_conv_dgrad_fused: g / y2 / dy_out");
+  SST_REQUIRE((epi_partial == nullptr) == (epi_y == nullptr), "sst_conv_dgrad_fused: epi_y and epi_partial come together");
+  return conv_fwd_impl(g, wp, out, nullptr, nullptr, in_scale, in_shift, in_slope, in_slope_const, in_act, residual, nullptr,
+                       nullptr, OUT_NHWC, B, H, W, Cin, Cout, ksize, 1, epi_y, epi_scale, epi_shift, epi_slope, epi_slope_const,
+                       epi_act, epi_partial, stream, y2, cA, cB, cC, dy_out);
+}
+
 // ---- data-gradient of a 3x3 stride-2 pad-1 convolution (Discriminator.features, model.py:35,42,49,56)
 SST_API int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin) { return s2_class_offset(4, Cin, Cout); }
 
@@ -587,6 +642,7 @@ SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B
     a.in_scale = a.in_shift = a.in_slope = nullptr; a.in_slope_const = 0.f; a.in_act = ACT_NONE;
     a.residual = nullptr; a.stats = nullptr; a.stats_cnt = nullptr; a.out_mode = OUT_STRIDE2; a.dbg = 0;
     a.epi_y = a.epi_scale = a.epi_shift = a.epi_slope = nullptr; a.epi_slope_const = 0.f; a.epi_act = 0; a.epi_partial = nullptr;
+    a.in2 = a.in_cA = a.in_cB = a.in_cC = nullptr; a.side_out = nullptr;
     a.B = B; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin;     // roles swap: the "input" of this conv is dy
     a.ksy = 1 + py; a.ksx = 1 + px; a.pad_y = a.pad_x = 0; a.sub_y = py; a.sub_x = px;
     a.Ho = nh; a.Wo = nw; a.Hy = H; a.Wy = W;

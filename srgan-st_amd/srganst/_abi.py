@@ -31,6 +31,8 @@ SIGNATURES = {
     "sst_conv_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_dgrad_bwdstats": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_dgrad_fused": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, P, P, c_float, c_int, P,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_wgrad_chunks": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_wgrad": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, P]),

@@ -179,22 +179,21 @@ def backward(module, params, sv, dsr, need_dx=False):
         first = i == 0
         h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2 = sv["blocks"][i]
         sl = p[pre + ".2.weight"]
-        dy2 = ops.bwd_finalize_apply(part, dh, y2, n, scale=s2, shift=t2, mean=m2, rstd=r2, gamma=p[pre + ".4.weight"],
-                                     dgamma=grads[pre + ".4.weight"], dbeta=grads[pre + ".4.bias"])
+        # stage 2 (BN2, no activation): finalize -> [apply + dgrad conv_b + partials for stage 1] in one launch
+        cA, cB, cC = ops.bwd_finalize(part, n, m2, r2, p[pre + ".4.weight"], grads[pre + ".4.weight"], grads[pre + ".4.bias"])
+        dp1, dy2, part = ops.conv_dgrad_fused(dh, y2, wd[pre + ".3.weight"], C, 3, cA, cB, cC, epi_y=y1, epi_scale=s1,
+                                              epi_shift=t1, epi_slope=sl, epi_act=1)
         with ops.SideStream(y1, dy2, grads[pre + ".3.weight"]):
             ops.conv_wgrad(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
-        dp1, part = ops.conv_dgrad_bwdstats(dy2, wd[pre + ".3.weight"], C, 3, y1, epi_scale=s1, epi_shift=t1, epi_slope=sl,
-                                            epi_act=1)
-        dy1 = ops.bwd_finalize_apply(part, dp1, y1, n, scale=s1, shift=t1, slope=sl, act=1, mean=m1, rstd=r1,
-                                     gamma=p[pre + ".1.weight"], dgamma=grads[pre + ".1.weight"],
-                                     dbeta=grads[pre + ".1.bias"], dslope=grads[pre + ".2.weight"])
+        # stage 1 (BN1 + PReLU)
+        cA, cB, cC = ops.bwd_finalize(part, n, m1, r1, p[pre + ".1.weight"], grads[pre + ".1.weight"], grads[pre + ".1.bias"],
+                                      dslope=grads[pre + ".2.weight"])
+        prev_y2 = None if first else sv["blocks"][i - 1][6]
+        dh, dy1, part = ops.conv_dgrad_fused(dp1, y1, wd[pre + ".0.weight"], C, 3, cA, cB, cC, in_scale=s1, in_shift=t1,
+                                             in_slope=sl, in_act=ACT_SLOPE, residual=dh, epi_y=prev_y2)
         with ops.SideStream(h, dy1, grads[pre + ".0.weight"]):
             ops.conv_wgrad(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None,
                            in_act=ACT_SLOPE if first else 0)
-        if first:
-            dh = ops.conv_fwd(dy1, wd[pre + ".0.weight"], C, 3, 1, residual=dh)[0]
-        else:
-            dh, part = ops.conv_dgrad_bwdstats(dy1, wd[pre + ".0.weight"], C, 3, sv["blocks"][i - 1][6], residual=dh)
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
     dz1 = ops.bwd_reduce_apply(dh, z1, n, g2=dskip, slope=a1, act=1, dbeta=grads["conv1.0.bias"],

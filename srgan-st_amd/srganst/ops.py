@@ -569,3 +569,27 @@ def bwd_finalize_apply(part, g, y, n, g2=None, scale=None, shift=None, slope=Non
     cA, cB, cC = bwd_finalize(part, n, mean, rstd, gamma, dgamma, dbeta, dslope, accumulate)
     return bwd_apply(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act, cA=cA, cB=cB, cC=cC,
                      unshuffle=unshuffle)
+
+
+def conv_dgrad_fused(g, y2, wd, cout, ksize, cA=None, cB=None, cC=None, in_scale=None, in_shift=None, in_slope=None,
+                     in_slope_const=0.0, in_act=0, residual=None, epi_y=None, epi_scale=None, epi_shift=None, epi_slope=None,
+                     epi_slope_const=0.0, epi_act=0):
+    """One BatchNorm-backward stage in one launch: dy = BN/activation backward of g against y2 (computed while staging,
+    also returned for the weight gradient), out = stride-1 data-gradient conv(dy) (+ residual), optional backward
+    partials of `out` against epi_y.  Returns (out, dy, partial | None)."""
+    B, H, W, cin = g.shape
+    out = _f32(B, H, W, cout, like=g)
+    dy = torch.empty_like(g)
+    partial = None
+    if epi_y is not None:
+        partial = _f32(_abi.lib().sst_conv_mtiles(B, H, W), 3, cout, like=g)
+    args = (ptr(g), ptr(y2), ptr(cA), ptr(cB), ptr(cC), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const),
+            int(in_act), ptr(dy), ptr(wd), ptr(out), ptr(residual), ptr(epi_y), ptr(epi_scale), ptr(epi_shift), ptr(epi_slope),
+            float(epi_slope_const), int(epi_act), ptr(partial), B, H, W, cin, cout, ksize)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv_dgrad_fused(*args, stream_ptr()), "sst_conv_dgrad_fused")
+    flops = 2.0 * B * H * W * cout * cin * ksize * ksize
+    _prof_end(e0, f"conv_fwd_kernel<{ksize},1>", flops)
+    _trace(f"conv_fwd_kernel<{ksize},1>", flops, lambda: _abi.lib().sst_conv_dgrad_fused(*args, stream_ptr()),
+           g, y2, cA, cB, cC, in_scale, in_shift, in_slope, dy, wd, out, residual, epi_y, epi_scale, epi_shift, epi_slope, partial)
+    return out, dy, partial
