@@ -108,7 +108,7 @@ def kernel_roofline(workload, device, hr, B):
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get(dom)
+            traffic = json.load(open(tf)).get(workload, {}).get(dom)
         except Exception:
             traffic = None
     return {"bound": "mfma", "kernel": dom, "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
