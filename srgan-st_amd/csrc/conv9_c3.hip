@@ -94,19 +94,32 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
     }
     __syncthreads();
     const int npair = (tw + 1) >> 1;
-    for (int kk = 0; kk < npair; ++kk) {
+    // operands of pair kk+1 are read from LDS while the (<= MAXU) MFMAs of pair kk run
+    float av[MAXU], bv[MAXU];
+    auto load_pair = [&](int kk, float (&A)[MAXU], float (&Bv)[MAXU]) {
       const int px = 2 * kk + lh;
       const bool pv = px < tw;
-      // window offset of this lane's column q = li in the band row: conv1: 3*px + q ; conv3: 3*px + 26 - q
-      const int so = 8 + 3 * px + (a.kind ? li : 26 - li);
+      const int so = 8 + 3 * px + (a.kind ? li : 26 - li);   // window offset of column q = li: conv1 3*px+q ; conv3 3*px+26-q
 #pragma unroll
       for (int u = 0; u < MAXU; ++u) {
-        const int unit = wave + 4 * u;
-        if (unit < nunits) {                     // wave-uniform
-          const float av = pv ? sB[px * CL + u_fr[u]] : 0.f;
-          const float bv = pv ? sS[ry * RS + u_br[u] + so] : 0.f;   // band row 0 is image row y0-4
-          acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u], 0, 0, 0);
+        if (wave + 4 * u < nunits) {                         // wave-uniform
+          A[u] = pv ? sB[px * CL + u_fr[u]] : 0.f;
+          Bv[u] = pv ? sS[ry * RS + u_br[u] + so] : 0.f;    // band row 0 is image row y0-4
         }
+      }
+    };
+    load_pair(0, av, bv);
+    for (int kk = 0; kk < npair; ++kk) {
+      float an[MAXU], bn[MAXU];
+      load_pair(kk + 1 < npair ? kk + 1 : kk, an, bn);
+#pragma unroll
+      for (int u = 0; u < MAXU; ++u) {
+        if (wave + 4 * u < nunits) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < MAXU; ++u) {
+        av[u] = an[u];
+        bv[u] = bn[u];
       }
     }
   }
@@ -130,26 +143,32 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
 // conv1: dW[co][ci][ky][kx] = sum_wg slab[wg][ky][co][3kx + ci]            (Cout = C, Cin = 3)
 __global__ __launch_bounds__(256) void c3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nwg, int C,
                                                         int kind, int accumulate) {
+  // 16 lanes per output element split the nwg slabs (fixed assignment + fixed shuffle tree => reproducible)
   const int total = 9 * C * 27;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+  const int sub = threadIdx.x & 15;
+  for (int i = blockIdx.x * 16 + (threadIdx.x >> 4); i < total; i += gridDim.x * 16) {
     const int q = i % 27, t = i / 27, ch = t % C, ky = t / C;
     float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += slab[((size_t)(w * 9 + ky) * C + ch) * 32 + q];
-    int co, ci, kx;
-    if (kind == 0) {            // q = 3kx - co + 2
-      kx = (q + 0) / 3;         // q+.. : co = 3kx + 2 - q in {0,1,2}
-      co = 3 * kx + 2 - q;
-      if (co > 2) { kx -= 1; co -= 3; }
-      if (co < 0) { kx += 1; co += 3; }
-      ci = ch;
-    } else {                    // q = 3kx + ci
-      kx = q / 3;
-      ci = q - 3 * kx;
-      co = ch;
+    for (int w = sub; w < nwg; w += 16) s += slab[((size_t)(w * 9 + ky) * C + ch) * 32 + q];
+    s += __shfl_xor(s, 8, 16);
+    s += __shfl_xor(s, 4, 16);
+    s += __shfl_xor(s, 2, 16);
+    s += __shfl_xor(s, 1, 16);
+    if (sub == 0) {
+      int co, ci, kx;
+      if (kind == 0) {            // q = 3kx - co + 2  ->  co = 3kx + 2 - q in {0,1,2}
+        kx = q / 3;
+        co = 3 * kx + 2 - q;
+        ci = ch;
+      } else {                    // q = 3kx + ci
+        kx = q / 3;
+        ci = q - 3 * kx;
+        co = ch;
+      }
+      const int Cin = kind == 0 ? C : 3;
+      float* d = dw + (((size_t)co * Cin + ci) * 9 + ky) * 9 + kx;
+      *d = accumulate ? *d + s : s;
     }
-    const int Cin = kind == 0 ? C : 3;
-    float* d = dw + (((size_t)co * Cin + ci) * 9 + ky) * 9 + kx;
-    *d = accumulate ? *d + s : s;
   }
 }
 
@@ -186,7 +205,7 @@ SST_API int sst_wgrad_c3(const float* big, const float* small, float* slab, floa
   }
   wgrad_c3_kernel<<<nwg, CONV_NT, smem, sst_stream(stream)>>>(a);
   SST_LAUNCH_CHECK("wgrad_c3_kernel");
-  c3_reduce_kernel<<<(9 * C * 27 + 255) / 256, 256, 0, sst_stream(stream)>>>(slab, dw, nwg, C, kind, accumulate);
+  c3_reduce_kernel<<<(9 * C * 27 + 15) / 16, 256, 0, sst_stream(stream)>>>(slab, dw, nwg, C, kind, accumulate);
   SST_LAUNCH_CHECK("c3_reduce_kernel");
   return SST_OK;
 }

@@ -31,6 +31,8 @@ struct WgradArgs {
   int dbg;                 // dev ablation bits from $SST_WGRAD_DBG (0 in production): 1 no global loads, 2 no MFMA, 4 no slab store
 };
 
+// VEC: Cin % 4 == 0 and Cout % 4 == 0 (every hot-path layer) - the scalar-tail code is compiled out.
+template <bool VEC>
 __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float sX[SUB * WLD];
   __shared__ __attribute__((aligned(16))) float sD[SUB * WLD];
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
   const int64_t m_begin = (int64_t)blockIdx.x * a.chunk_px;
   const int64_t m_end = min(M, m_begin + a.chunk_px);
   const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
-  const bool xvec = (a.Cin & 3) == 0, dvec = (a.Cout & 3) == 0;
+  const bool xvec = VEC || (a.Cin & 3) == 0, dvec = VEC || (a.Cout & 3) == 0;
   const int wco = (wave & 1) * 32, wci = (wave >> 1) * 32;
 
   f32x16 acc;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
         const int c = ci0 + c4;
         if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.Cin) {
           const float* src = a.x + (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + c;
-          if (xvec) {
+          if (VEC || xvec) {
             xv = *reinterpret_cast<const f32x4*>(src);
           } else {
 #pragma unroll
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
         const int co = co0 + c4;
         if (co < a.Cout) {
           const float* src = a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
-          if (dvec) {
+          if (VEC || dvec) {
             dv = *reinterpret_cast<const f32x4*>(src);
           } else {
 #pragma unroll
@@ -141,9 +143,11 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) xv[j] = xv[j] > 0.f ? xv[j] : xv[j] * slope;
         }
+        if (!VEC) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c + j >= a.Cin) xv[j] = 0.f;
+          for (int j = 0; j < 4; ++j)
+            if (c + j >= a.Cin) xv[j] = 0.f;
+        }
       } else {
         xv = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -158,11 +162,18 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
     __syncthreads();
     if (m0 + SUB < m_end) stage_load(m0 + SUB);
     // ---- 32 MFMAs: K = 64 pixels, 2 per instruction (lane half lh picks the pixel of the pair)
-#pragma unroll 8
-    for (int kk = 0; kk < ((a.dbg & 2) ? 0 : SUB / 2); ++kk) {
-      const float av = sD[(2 * kk + lh) * WLD + wco + li];
-      const float bv = sX[(2 * kk + lh) * WLD + wci + li];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    if (!(a.dbg & 2)) {
+      // fragments of step kk+1 are read from LDS while the MFMA of step kk runs (explicit 1-deep software pipeline)
+      float av = sD[lh * WLD + wco + li], bv = sX[lh * WLD + wci + li];
+#pragma unroll
+      for (int kk = 0; kk < SUB / 2; ++kk) {
+        const int kn = (kk + 1 < SUB / 2) ? kk + 1 : kk;
+        const float an = sD[(2 * kn + lh) * WLD + wco + li];
+        const float bn = sX[(2 * kn + lh) * WLD + wci + li];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        av = an;
+        bv = bn;
+      }
     }
   }
   // ---- store the partial tile: rows = co, cols = ci (lanes contiguous along ci)
@@ -249,7 +260,10 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   }
   const int KK = ksize * ksize;
   dim3 grid(nchunk, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
-  conv_wgrad_kernel<<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+  if ((Cin & 3) == 0 && (Cout & 3) == 0)
+    conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+  else
+    conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
   SST_LAUNCH_CHECK("conv_wgrad_kernel");
   const int64_t total = (int64_t)KK * Cout * Cin;
   const int64_t items = (Cin & 3) == 0 ? total / 4 : total;
