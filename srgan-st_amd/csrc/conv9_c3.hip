@@ -31,6 +31,9 @@ struct WgC3Args {
   int nrc, nxc;            // row chunks, x chunks per image
 };
 
+// NU = (ky, channel-fragment) units per wave, compile-time so that the unit loops unroll without branches
+// (only the LAST unit of a wave can be missing: 9*nfrag units are dealt round-robin over 4 waves).
+template <int NU>
 __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
   float* sS = lds + TXMAX * CL;                  // [TR+8][RS]   rows y0-4 .. y0+TR+3, pixels x0-4 .. x0+tw+3
   const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
   const int nunits = 9 * nfrag;
+  const bool last_ok = wave + 4 * (NU - 1) < nunits;
 
   // ---- the small-operand band (zero outside the image)
   for (int i = tid; i < (TR + 8) * RS; i += CONV_NT) {
@@ -60,16 +64,16 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
     sS[i] = v;
   }
 
-  f32x16 acc[MAXU];
+  f32x16 acc[NU];
 #pragma unroll
-  for (int u = 0; u < MAXU; ++u)
+  for (int u = 0; u < NU; ++u)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
 
   // per-unit constants (wave-uniform): channel-fragment offset and band-row offset
-  int u_fr[MAXU], u_br[MAXU];
+  int u_fr[NU], u_br[NU];
 #pragma unroll
-  for (int u = 0; u < MAXU; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int unit = wave + 4 * u;
     const int ky = unit / nfrag, fr = unit - ky * nfrag;
     u_fr[u] = fr * 32 + li;
@@ -95,14 +99,14 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
     __syncthreads();
     const int npair = (tw + 1) >> 1;
     // operands of pair kk+1 are read from LDS while the (<= MAXU) MFMAs of pair kk run
-    float av[MAXU], bv[MAXU];
-    auto load_pair = [&](int kk, float (&A)[MAXU], float (&Bv)[MAXU]) {
+    float av[NU], bv[NU];
+    auto load_pair = [&](int kk, float (&A)[NU], float (&Bv)[NU]) {
       const int px = 2 * kk + lh;
       const bool pv = px < tw;
       const int so = 8 + 3 * px + (a.kind ? li : 26 - li);   // window offset of column q = li: conv1 3*px+q ; conv3 3*px+26-q
 #pragma unroll
-      for (int u = 0; u < MAXU; ++u) {
-        if (wave + 4 * u < nunits) {                         // wave-uniform
+      for (int u = 0; u < NU; ++u) {
+        if (u < NU - 1 || last_ok) {                         // wave-uniform; compile-time true except for the last unit
           A[u] = pv ? sB[px * CL + u_fr[u]] : 0.f;
           Bv[u] = pv ? sS[ry * RS + u_br[u] + so] : 0.f;    // band row 0 is image row y0-4
         }
@@ -110,14 +114,14 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
     };
     load_pair(0, av, bv);
     for (int kk = 0; kk < npair; ++kk) {
-      float an[MAXU], bn[MAXU];
+      float an[NU], bn[NU];
       load_pair(kk + 1 < npair ? kk + 1 : kk, an, bn);
 #pragma unroll
-      for (int u = 0; u < MAXU; ++u) {
-        if (wave + 4 * u < nunits) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[u], 0, 0, 0);
+      for (int u = 0; u < NU; ++u) {
+        if (u < NU - 1 || last_ok) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[u], 0, 0, 0);
       }
 #pragma unroll
-      for (int u = 0; u < MAXU; ++u) {
+      for (int u = 0; u < NU; ++u) {
         av[u] = an[u];
         bv[u] = bn[u];
       }
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
   // ---- partial slab: [wg][ky][C][32]
   float* out = a.slab + (size_t)wg * 9 * a.C * 32;
 #pragma unroll
-  for (int u = 0; u < MAXU; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int unit = wave + 4 * u;
     if (unit < nunits) {
       const int ky = unit / nfrag, fr = unit - ky * nfrag;
@@ -198,12 +202,20 @@ SST_API int sst_wgrad_c3(const float* big, const float* small, float* slab, floa
   const int nfrag = (C + 31) / 32;
   const int nwg = B * a.nrc * a.nxc;
   const size_t smem = ((size_t)TXMAX * (nfrag * 32 + 4) + (size_t)(TR + 8) * ((TXMAX + 8) * 3 + 16)) * sizeof(float);
+  const int nu = (9 * nfrag + 3) / 4;     // units per wave (3, 5, 7 or 9)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c3_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c3_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_c3_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  wgrad_c3_kernel<<<nwg, CONV_NT, smem, sst_stream(stream)>>>(a);
+  hipStream_t st = sst_stream(stream);
+  if (nu <= 3) wgrad_c3_kernel<3><<<nwg, CONV_NT, smem, st>>>(a);
+  else if (nu <= 5) wgrad_c3_kernel<5><<<nwg, CONV_NT, smem, st>>>(a);
+  else if (nu <= 7) wgrad_c3_kernel<7><<<nwg, CONV_NT, smem, st>>>(a);
+  else wgrad_c3_kernel<9><<<nwg, CONV_NT, smem, st>>>(a);
   SST_LAUNCH_CHECK("wgrad_c3_kernel");
   c3_reduce_kernel<<<(9 * C * 27 + 15) / 16, 256, 0, sst_stream(stream)>>>(slab, dw, nwg, C, kind, accumulate);
   SST_LAUNCH_CHECK("c3_reduce_kernel");
