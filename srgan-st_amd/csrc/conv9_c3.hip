@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int TR = 6;        // rows per workgroup
+constexpr int TR = 3;        // rows per workgroup (2 co-resident workgroups per CU at 96x96, B=16)
 constexpr int TXMAX = 96;    // pixels per row segment
 constexpr int MAXU = 9;      // (ky, channel-fragment) units per wave  -> C <= 128
 
