@@ -49,6 +49,7 @@ int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksize, int m
  * long long total, block_begin;} (48 bytes each; each workgroup packs 1024 floats) */
 int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, void* stream);
 int sst_conv_mtiles(int B, int Ho, int Wo);
+long sst_debug_big_tile_launches(void);   /* test hook: launches of the 64x64-tile conv kernel so far */
 int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,
                  const float* in_scale, const float* in_shift, const float* in_slope,
                  float in_slope_const, int in_act, const float* residual, float* stats,

@@ -4,8 +4,7 @@
 #pragma once
 #include "conv_common.h"
 
-namespace {
-
+// (types at namespace scope: they cross translation units through sst_launch_conv_fwd2)
 constexpr int TWO = 8, THO = 4;   // output tile (pixels)
 
 struct Conv3Args {
@@ -48,6 +47,8 @@ enum : int {
   OUT_STRIDE2 = 4,      // y[b, 2oy+sub_y, 2ox+sub_x, c] = out (y is [B,Hy,Wy,Cout]: data-gradient of a stride-2 conv, one parity class)
 };
 
+
+namespace {
 
 // Epilogue of ONE 32-pixel (8 wide x 4 high at (oy0, ox0)) x 32-channel (block nf) tile whose K-partials sit in the
 // 4 waves' accumulators.  mt = statistics-tile index (8x4 tiling of the output); tile_ok = the tile has valid pixels.

@@ -19,10 +19,23 @@
 // Epilogue: + bias, + residual, per-tile BatchNorm partial statistics (sum, centred M2; combined
 // with Chan's formula by bn_finalize - no atomics, bit-reproducible).
 #include "conv_common.h"
-
+#include <cstdlib>
 #include "conv_epilogue.h"
 
+// 64x64-tile variant (conv_fwd2.hip)
+int sst_launch_conv_fwd2(const Conv3Args& a, int stride, hipStream_t st);
+
 namespace {
+
+// Use the 64 px x 64 ch tile kernel when the layer still yields enough workgroups to fill the chip with it.
+constexpr int BIG_MIN_TILES = 2048;   // measured (tools/ablate_big.py): +9 % at >= 2304 tiles, slower below ~1500
+inline bool use_big_tiles(const Conv3Args& a, int ksize) {
+  if (ksize != 3 || a.Cout < 64 || a.in2 || a.side_out) return false;
+  if (a.out_mode != OUT_NHWC && a.out_mode != OUT_SHUFFLE && a.out_mode != OUT_STRIDE2) return false;
+  if (const char* e = getenv("SST_CONV_BIG")) return atoi(e) != 0;       // dev override
+  const long tiles = (long)a.B * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) * ((a.Cout + 63) / 64);
+  return tiles >= BIG_MIN_TILES;
+}
 
 template <int KS, int S>
 __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
@@ -370,6 +383,7 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   hipStream_t st = sst_stream(stream);
   const size_t extra_lds = (size_t)(dbg_bits >> 4) * 1024;   // dev knob: pad LDS to cap workgroups per CU
   a.dbg = dbg_bits & 15;
+  if (dbg_bits == 0 && use_big_tiles(a, ksize)) return sst_launch_conv_fwd2(a, stride, st);
   if (ksize == 3 && stride == 1)
     conv_fwd_kernel<3, 1><<<grid, CONV_NT, extra_lds, st>>>(a);
   else if (ksize == 3)
@@ -447,6 +461,11 @@ SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B
     a.B = B; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin;     // roles swap: the "input" of this conv is dy
     a.ksy = 1 + py; a.ksx = 1 + px; a.pad_y = a.pad_x = 0; a.sub_y = py; a.sub_x = px;
     a.Ho = nh; a.Wo = nw; a.Hy = H; a.Wy = W;
+    if (use_big_tiles(a, 3)) {
+      const int rc = sst_launch_conv_fwd2(a, 1, sst_stream(stream));
+      if (rc != SST_OK) return rc;
+      continue;
+    }
     dim3 grid((unsigned)sst_conv_mtiles(B, nh, nw), (Cin + 31) / 32);
     conv_fwd_kernel<3, 1><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
     SST_LAUNCH_CHECK("conv_fwd_kernel<3,1> (s2 dgrad)");

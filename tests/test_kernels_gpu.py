@@ -250,3 +250,54 @@ def test_conv9_folded_forward_kernels(ops, case):
     F.conv2d(p, w3.double(), None, 1, 4).backward(dy.double())
     dp = ops.conv9_c3_fwd(nhwc(dy).cuda(), w3.cuda(), 1)
     assert rel_err(nchw(dp.cpu()), p.grad) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 48, 48, 64, 256, 1), (1, 24, 24, 64, 128, 2), (2, 13, 21, 8, 96, 1), (1, 16, 16, 128, 64, 1),
+                                  (1, 9, 9, 64, 64, 2), (1, 12, 12, 256, 512, 1)])
+def test_conv_big_tile_kernel(ops, case, monkeypatch):
+    """The 64x64-tile kernel (forced with SST_CONV_BIG=1) against fp64 conv2d: plain / prologue+stats+residual / shuffle /
+    data-gradient with backward partials."""
+    monkeypatch.setenv("SST_CONV_BIG", "1")
+    from srganst import _abi
+    n_before = _abi.lib().sst_debug_big_tile_launches()
+    B, H, W, Cin, Cout, s = case
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    xin = F.leaky_relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2)
+    ref = F.conv2d(xin, w.double(), bias.double(), s, 1)
+    res = torch.randn(ref.shape, generator=g)
+    wp = ops.pack_conv(w.cuda())
+    y, _, stats, cnt = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, 3, s, bias=bias.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(),
+                                    in_slope_const=0.2, in_act=ops.ACT_SLOPE, residual=nhwc(res).cuda(), want_stats=True)
+    full = ref + res.double()
+    assert rel_err(nchw(y.cpu()), full) < TOL
+    mean, rstd, _, _ = ops.bn_finalize(stats, cnt, torch.ones(Cout).cuda(), torch.zeros(Cout).cuda())
+    assert rel_err(mean.cpu(), full.mean(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(rstd.cpu(), 1 / torch.sqrt(full.var(dim=(0, 2, 3), unbiased=False) + 1e-5)) < 1e-4
+    if s == 1 and Cout % 4 == 0:
+        ysh = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, 3, 1, out_mode=ops.OUT_SHUFFLE)[0]
+        assert rel_err(nchw(ysh.cpu()), F.pixel_shuffle(F.conv2d(x.double(), w.double(), None, 1, 1), 2)) < TOL
+        # data-gradient + backward partials against a saved tensor
+        dy = torch.randn(B, Cout, H, W, generator=g)
+        ysave = torch.randn(B, Cin, H, W, generator=g)
+        gref = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy.double(), 1, 1)
+        gd, part = ops.conv_dgrad_bwdstats(nhwc(dy).cuda(), ops.pack_conv(w.cuda(), 1), Cin, 3, nhwc(ysave).cuda(),
+                                           epi_scale=sc.cuda(), epi_shift=sh.cuda(), epi_slope_const=0.2, epi_act=1)
+        assert rel_err(nchw(gd.cpu()), gref) < TOL
+        z = ysave.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        gz = torch.where(z > 0, gref, gref * 0.2)
+        tot = part.sum(dim=0).cpu()
+        assert rel_err(tot[0], gz.sum(dim=(0, 2, 3))) < 1e-4
+        assert rel_err(tot[1], (gz * ysave.double()).sum(dim=(0, 2, 3))) < 1e-4
+        assert rel_err(tot[2], (gref * z.clamp(max=0)).sum(dim=(0, 2, 3))) < 1e-4
+    else:
+        xg = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+        yy = F.conv2d(xg, w.double(), None, 2, 1)
+        dy = torch.randn(yy.shape, generator=g)
+        yy.backward(dy.double())
+        dx = ops.conv_s2_dgrad(nhwc(dy).cuda(), ops.pack_conv_s2_dgrad(w.cuda()), H, W, Cin)
+        assert rel_err(nchw(dx.cpu()), xg.grad) < TOL
+    assert _abi.lib().sst_debug_big_tile_launches() >= n_before + 2      # the 64x64 kernel really ran
