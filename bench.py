@@ -225,6 +225,8 @@ def main():
         if args.hr != 96:
             wl = wl.replace("hr96", f"hr{args.hr}")
             flop_img *= (args.hr / 96.0) ** 2
+        if B != 16:
+            wl = wl.replace("_b16_", f"_b{B}_")
         out = {"metric": "HR images/sec (96px x4, B=16/GPU) training step", "value": imgs, "unit": "HR images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -60,9 +60,11 @@ def forward(module, x, p, training):
 
 def backward(module, p, sv, dout, need_param_grads, need_dx):
     grads = {}
+    names = list(p.keys())
+    views = ops.flat_grads(module, names, [p[n] for n in names]) if need_param_grads else {}
 
     def G(name):
-        t = torch.empty_like(p[name])
+        t = views[name]
         grads[name] = t
         return t
 

@@ -75,6 +75,35 @@ def allreduce_grads(params, pg=None, buckets: int = 1, force: bool = False) -> N
             g.copy_(f)
 
 
+def allreduce_module_grads(module, pg=None, buckets: int = 1, force: bool = False) -> None:
+    """Like allreduce_grads(module.parameters()), but if the module's backward left its gradients as views of one
+    flat buffer (srganst graphs do: module._flat_grad) and they still live there, that buffer is all-reduced in place -
+    one message (or `buckets` contiguous slices of it), no flatten / unflatten copies."""
+    world = world_size(pg)
+    if world == 1 and not (force and td.is_available() and td.is_initialized()):
+        return
+    ps = [p for p in module.parameters() if p.grad is not None]
+    flat = None
+    for cand in reversed(module.__dict__.get("_flat_grads", [])):
+        lo, hi = cand.data_ptr(), cand.data_ptr() + cand.numel() * 4
+        if ps and all(lo <= p.grad.data_ptr() < hi and p.grad.is_contiguous() for p in ps) and \
+                sum(p.grad.numel() for p in ps) == cand.numel():
+            flat = cand
+            break
+    if flat is None:
+        return allreduce_grads(ps, pg, buckets, force)
+    n = flat.numel()
+    step = (n + buckets - 1) // buckets
+    handles = []
+    for i in range(0, n, step):
+        sl = flat[i:i + step]
+        handles.append((td.all_reduce(sl, op=td.ReduceOp.SUM, group=pg, async_op=True), sl))
+    for h, sl in handles:
+        h.wait()
+        if world > 1:
+            sl.mul_(1.0 / world)
+
+
 def broadcast_module(module, src: int = 0, pg=None) -> None:
     """Make parameters and buffers identical on every rank (rank `src` wins)."""
     if world_size(pg) == 1:

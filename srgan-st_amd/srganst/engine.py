@@ -129,7 +129,7 @@ class WarmupEngine:
             self.lr.copy_(lr, non_blocking=True)
         self._fb()
         if self.dp:
-            sdist.allreduce_grads(self.G.parameters(), self.pg, force=True)
+            sdist.allreduce_module_grads(self.G, self.pg, force=True)
             self._op()
         return self.loss_values
 
@@ -218,13 +218,13 @@ class TrainEngine:
             self.lr.copy_(lr, non_blocking=True)
         self._g_fb()
         if self.world > 1:
-            sdist.allreduce_grads(self.G.parameters(), self.pg)
+            sdist.allreduce_module_grads(self.G, self.pg)
             self._g_op()
         did_d = False
         if self.batch_num % self.config.SOLVER.D_UPDATE_INTERVAL == 0:
             self._d_fb()
             if self.world > 1:
-                sdist.allreduce_grads(self.D.parameters(), self.pg, buckets=2 if self.config.DIST.BUCKET_D else 1)
+                sdist.allreduce_module_grads(self.D, self.pg, buckets=2 if self.config.DIST.BUCKET_D else 1)
                 self._d_op()
             did_d = True
         self.batch_num += 1

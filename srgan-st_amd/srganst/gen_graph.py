@@ -124,7 +124,7 @@ def forward(module, x, params, need_grad):
 def backward(module, params, sv, dsr, need_dx=False):
     """-> list of gradients in module._names order."""
     p = _P(module, params)
-    grads = {n: torch.empty_like(t) for n, t in zip(module._names, params)}
+    grads = ops.flat_grads(module, module._names, params)      # views of ONE flat buffer (single RCCL message)
     C = p["conv1.0.weight"].shape[0]
     a1 = p["conv1.1.weight"]
     wd = _packs(module, p, 1)

@@ -593,3 +593,20 @@ def conv_dgrad_fused(g, y2, wd, cout, ksize, cA=None, cB=None, cC=None, in_scale
     _trace(f"conv_fwd_kernel<{ksize},1>", flops, lambda: _abi.lib().sst_conv_dgrad_fused(*args, stream_ptr()),
            g, y2, cA, cB, cC, in_scale, in_shift, in_slope, dy, wd, out, residual, epi_y, epi_scale, epi_shift, epi_slope, partial)
     return out, dy, partial
+
+
+def flat_grads(module, names, params):
+    """One flat fp32 buffer + per-parameter views (reference order).  The buffer is remembered on the module so that
+    the data-parallel exchange can all-reduce it in place as ONE message (no flatten / unflatten copies)."""
+    total = sum(t.numel() for t in params)
+    flat = torch.empty(total, device=params[0].device, dtype=torch.float32)
+    views, off = {}, 0
+    for n, t in zip(names, params):
+        views[n] = flat[off:off + t.numel()].view(t.shape)
+        off += t.numel()
+    # remember the last few buffers: with two backward passes per step (D on gt and on sr) autograd accumulates into the
+    # FIRST pass's buffer, which is then the one holding p.grad
+    lst = module.__dict__.setdefault("_flat_grads", [])
+    lst.append(flat)
+    del lst[:-4]
+    return views
