@@ -87,7 +87,7 @@ def allreduce_module_grads(module, pg=None, buckets: int = 1, force: bool = Fals
     for cand in reversed(module.__dict__.get("_flat_grads", [])):
         lo, hi = cand.data_ptr(), cand.data_ptr() + cand.numel() * 4
         if ps and all(lo <= p.grad.data_ptr() < hi and p.grad.is_contiguous() for p in ps) and \
-                sum(p.grad.numel() for p in ps) == cand.numel():
+                sum((p.grad.numel() + 15) // 16 * 16 for p in ps) == cand.numel():
             flat = cand
             break
     if flat is None:

@@ -598,12 +598,14 @@ def conv_dgrad_fused(g, y2, wd, cout, ksize, cA=None, cB=None, cC=None, in_scale
 def flat_grads(module, names, params):
     """One flat fp32 buffer + per-parameter views (reference order).  The buffer is remembered on the module so that
     the data-parallel exchange can all-reduce it in place as ONE message (no flatten / unflatten copies)."""
-    total = sum(t.numel() for t in params)
-    flat = torch.empty(total, device=params[0].device, dtype=torch.float32)
-    views, off = {}, 0
-    for n, t in zip(names, params):
-        views[n] = flat[off:off + t.numel()].view(t.shape)
-        off += t.numel()
+    # every view starts on a 64-byte boundary: the fused multi-tensor Adam falls off its vectorised path on
+    # misaligned gradients (measured 2x slower); the padding words are don.t-care (also in the all-reduce)
+    offs, off = [], 0
+    for t in params:
+        offs.append(off)
+        off += (t.numel() + 15) // 16 * 16
+    flat = torch.empty(off, device=params[0].device, dtype=torch.float32)      # pad words are never read by anyone who cares
+    views = {n: flat[o:o + t.numel()].view(t.shape) for n, t, o in zip(names, params, offs)}
     # remember the last few buffers: with two backward passes per step (D on gt and on sr) autograd accumulates into the
     # FIRST pass's buffer, which is then the one holding p.grad
     lst = module.__dict__.setdefault("_flat_grads", [])
