@@ -103,6 +103,14 @@ int sst_conv_s2_dgrad_pack(const float* w, float* wp, int Cout, int Cin, void* s
 int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout,
                       void* stream);
 
+/* weight gradients of njobs layers of IDENTICAL shape in ONE launch (the 33 trunk-shaped convs of the generator):
+ * jobs = device array of {const float* x, *dy; float* slab, *dw; const float* in_scale, *in_shift, *in_slope;
+ * float in_slope_const; int in_act;} (64 bytes each). */
+/* writes nwords 64-bit words into device memory with a kernel whose ARGUMENTS carry them (graph-capturable) */
+int sst_fill_table(void* dst, const long long* host_words, int nwords, void* stream);
+int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, int W, int Cin, int Cout, int stride,
+                           int ksize, int accumulate, void* stream);
+
 /* ---- BatchNorm (train mode) + elementwise glue, tensors viewed as [R rows, C channels] -----------
  * nn.BatchNorm2d model.py:36-57,114,174,177 (eps 1e-5, momentum .1); PReLU/LeakyReLU backward;
  * residual adds model.py:146,183. */

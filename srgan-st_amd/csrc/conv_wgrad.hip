@@ -17,7 +17,16 @@ namespace {
 constexpr int SUB = 64;          // pixels per staged sub-tile
 constexpr int WLD = 64 + 4;      // LDS row stride (floats)
 
+// Grouped launch: many layers of identical shape in ONE launch (their per-layer pointers live in a device table).
+struct WgJob {
+  const float* x; const float* dy; float* slab; float* dw;
+  const float* in_scale; const float* in_shift; const float* in_slope;
+  float in_slope_const; int in_act;
+};
+
 struct WgradArgs {
+  const WgJob* jobs;       // null: single layer (fields below); else blockIdx.x = job * nchunk + chunk
+  int nchunk;
   const float* x;          // [B,H,W,Cin]
   const float* dy;         // [B,Ho,Wo,Cout]
   float* slab;             // [nchunk][KK][Cout][Cin]
@@ -34,6 +43,14 @@ struct WgradArgs {
 // VEC: Cin % 4 == 0 and Cout % 4 == 0 (every hot-path layer) - the scalar-tail code is compiled out.
 template <bool VEC>
 __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
+  int chunk = blockIdx.x;
+  if (a.jobs) {                       // grouped: fetch this workgroup's layer (workgroup-uniform scalar loads)
+    const int job = blockIdx.x / a.nchunk;
+    chunk = blockIdx.x - job * a.nchunk;
+    const WgJob jb = a.jobs[job];
+    a.x = jb.x; a.dy = jb.dy; a.slab = jb.slab; a.in_scale = jb.in_scale; a.in_shift = jb.in_shift;
+    a.in_slope = jb.in_slope; a.in_slope_const = jb.in_slope_const; a.in_act = jb.in_act;
+  }
   __shared__ __attribute__((aligned(16))) float sX[SUB * WLD];
   __shared__ __attribute__((aligned(16))) float sD[SUB * WLD];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
@@ -43,7 +60,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
   const int cob = blockIdx.z / nci, cib = blockIdx.z - cob * nci;
   const int co0 = cob * 64, ci0 = cib * 64;
   const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
-  const int64_t m_begin = (int64_t)blockIdx.x * a.chunk_px;
+  const int64_t m_begin = (int64_t)chunk * a.chunk_px;
   const int64_t m_end = min(M, m_begin + a.chunk_px);
   const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
   const bool xvec = VEC || (a.Cin & 3) == 0, dvec = VEC || (a.Cout & 3) == 0;
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
     if (acc[0] == 12345.f) a.slab[0] = 1.f;
     return;
   }
-  float* out = a.slab + ((size_t)blockIdx.x * gridDim.y + tap) * a.Cout * a.Cin;
+  float* out = a.slab + ((size_t)chunk * gridDim.y + tap) * a.Cout * a.Cin;
   const int ci = ci0 + wci + li;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -192,7 +209,11 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
 
 // dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci]     (fixed chunk order: reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunk,
-                                                           int KK, int Cout, int Cin, int accumulate) {
+                                                           int KK, int Cout, int Cin, int accumulate, const WgJob* jobs) {
+  if (jobs) {                          // grouped: blockIdx.y = layer
+    slab = jobs[blockIdx.y].slab;
+    dw = jobs[blockIdx.y].dw;
+  }
   const int64_t per_tap = (int64_t)Cout * Cin, total = per_tap * KK;
   if ((Cin & 3) == 0) {
     const int64_t total4 = total >> 2;
@@ -245,6 +266,7 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   SST_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize & 1) && ksize <= 9,
               "sst_conv_wgrad: bad shape");
   WgradArgs a;
+  a.jobs = nullptr; a.nchunk = 0;
   a.x = x; a.dy = dy; a.slab = slab; a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
   a.in_slope_const = in_slope_const; a.in_act = in_act;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.KS = ksize; a.pad = ksize / 2;
@@ -268,7 +290,64 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   const int64_t total = (int64_t)KK * Cout * Cin;
   const int64_t items = (Cin & 3) == 0 ? total / 4 : total;
   const int rb = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
-  wgrad_reduce_kernel<<<rb, 256, 0, sst_stream(stream)>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate);
+  wgrad_reduce_kernel<<<rb, 256, 0, sst_stream(stream)>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate, nullptr);
   SST_LAUNCH_CHECK("wgrad_reduce_kernel");
+  return SST_OK;
+}
+
+// Device-side table writer: the words travel as KERNEL ARGUMENTS (by value), so the write is an ordinary
+// stream-ordered, graph-capturable launch - no host-to-device copy (which a hipGraph capture would refuse).
+namespace {
+constexpr int TABLE_WORDS = 448;                      // 3.5 KB of kernel arguments
+struct TableWords { long long v[TABLE_WORDS]; };
+__global__ void fill_table_kernel(long long* dst, TableWords w, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = w.v[i];
+}
+}  // namespace
+
+SST_API int sst_fill_table(void* dst, const long long* host_words, int nwords, void* stream) {
+  SST_REQUIRE(dst && host_words && nwords > 0, "sst_fill_table: bad argument");
+  for (int off = 0; off < nwords; off += TABLE_WORDS) {
+    TableWords w;
+    const int n = nwords - off < TABLE_WORDS ? nwords - off : TABLE_WORDS;
+    for (int i = 0; i < n; ++i) w.v[i] = host_words[off + i];
+    fill_table_kernel<<<1, 256, 0, sst_stream(stream)>>>(reinterpret_cast<long long*>(dst) + off, w, n);
+    SST_LAUNCH_CHECK("fill_table_kernel");
+  }
+  return SST_OK;
+}
+
+// Weight gradients of `njobs` layers of IDENTICAL shape in one launch (+ one grouped slab reduce).
+// jobs: device array of WgJob {x, dy, slab, dw, in_scale, in_shift, in_slope, in_slope_const, in_act} (64 bytes each);
+// every job's slab holds sst_conv_wgrad_chunks(...) * k*k*Cout*Cin floats.
+SST_API int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, int W, int Cin, int Cout, int stride, int ksize,
+                                   int accumulate, void* stream) {
+  static_assert(sizeof(WgJob) == 64, "WgJob layout");
+  SST_REQUIRE(jobs && njobs > 0 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize & 1) &&
+                  ksize <= 9, "sst_conv_wgrad_grouped: bad argument");
+  WgradArgs a;
+  a.jobs = reinterpret_cast<const WgJob*>(jobs);
+  a.x = a.dy = nullptr; a.slab = nullptr; a.in_scale = a.in_shift = a.in_slope = nullptr; a.in_slope_const = 0.f; a.in_act = 0;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.KS = ksize; a.pad = ksize / 2;
+  a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
+  a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+  const int64_t M = (int64_t)B * a.Ho * a.Wo;
+  SST_REQUIRE(M < (1ll << 31), "sst_conv_wgrad_grouped: too many pixels");
+  const int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
+  a.nchunk = nchunk;
+  a.chunk_px = (int)(((M + nchunk - 1) / nchunk + SUB - 1) / SUB * SUB);
+  a.dbg = 0;
+  const int KK = ksize * ksize;
+  dim3 grid((unsigned)nchunk * njobs, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
+  if ((Cin & 3) == 0 && (Cout & 3) == 0)
+    conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+  else
+    conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+  SST_LAUNCH_CHECK("conv_wgrad_kernel (grouped)");
+  const int64_t total = (int64_t)KK * Cout * Cin;
+  const int64_t items = (Cin & 3) == 0 ? total / 4 : total;
+  const int rb = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
+  wgrad_reduce_kernel<<<dim3(rb, njobs), 256, 0, sst_stream(stream)>>>(nullptr, nullptr, nchunk, KK, Cout, Cin, accumulate, a.jobs);
+  SST_LAUNCH_CHECK("wgrad_reduce_kernel (grouped)");
   return SST_OK;
 }

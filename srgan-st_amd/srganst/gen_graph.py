@@ -128,6 +128,7 @@ def backward(module, params, sv, dsr, need_dx=False):
     C = p["conv1.0.weight"].shape[0]
     a1 = p["conv1.1.weight"]
     wd = _packs(module, p, 1)
+    wg = ops.WgradGroup()            # the trunk-shaped weight gradients go out as ONE launch at the end
 
     def rows(t):
         return t.numel() // t.shape[-1]
@@ -162,9 +163,8 @@ def backward(module, params, sv, dsr, need_dx=False):
     n = rows(y3)
     dy3 = ops.bwd_reduce_apply(g, y3, n, scale=s3, shift=t3, mean=m3, rstd=r3, gamma=p["conv2.1.weight"],
                                dgamma=grads["conv2.1.weight"], dbeta=grads["conv2.1.bias"])
-    with ops.SideStream(sv["h_last"], dy3, grads["conv2.0.weight"]):
-        ops.conv_wgrad(sv["h_last"], dy3, grads["conv2.0.weight"], 3, 1,
-                       in_slope=a1 if not sv["blocks"] else None, in_act=ACT_SLOPE if not sv["blocks"] else 0)
+    wg.add(sv["h_last"], dy3, grads["conv2.0.weight"], 3, 1,
+           in_slope=a1 if not sv["blocks"] else None, in_act=ACT_SLOPE if not sv["blocks"] else 0)
     dskip = g
     nb = len(sv["blocks"])
     # every stride-1 data-gradient conv below also emits the BatchNorm-backward partial sums of its result against the
@@ -183,17 +183,14 @@ def backward(module, params, sv, dsr, need_dx=False):
         cA, cB, cC = ops.bwd_finalize(part, n, m2, r2, p[pre + ".4.weight"], grads[pre + ".4.weight"], grads[pre + ".4.bias"])
         dp1, dy2, part = ops.conv_dgrad_fused(dh, y2, wd[pre + ".3.weight"], C, 3, cA, cB, cC, epi_y=y1, epi_scale=s1,
                                               epi_shift=t1, epi_slope=sl, epi_act=1)
-        with ops.SideStream(y1, dy2, grads[pre + ".3.weight"]):
-            ops.conv_wgrad(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
+        wg.add(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
         # stage 1 (BN1 + PReLU)
         cA, cB, cC = ops.bwd_finalize(part, n, m1, r1, p[pre + ".1.weight"], grads[pre + ".1.weight"], grads[pre + ".1.bias"],
                                       dslope=grads[pre + ".2.weight"])
         prev_y2 = None if first else sv["blocks"][i - 1][6]
         dh, dy1, part = ops.conv_dgrad_fused(dp1, y1, wd[pre + ".0.weight"], C, 3, cA, cB, cC, in_scale=s1, in_shift=t1,
                                              in_slope=sl, in_act=ACT_SLOPE, residual=dh, epi_y=prev_y2)
-        with ops.SideStream(h, dy1, grads[pre + ".0.weight"]):
-            ops.conv_wgrad(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None,
-                           in_act=ACT_SLOPE if first else 0)
+        wg.add(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0)
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
     dz1 = ops.bwd_reduce_apply(dh, z1, n, g2=dskip, slope=a1, act=1, dbeta=grads["conv1.0.bias"],
@@ -203,6 +200,7 @@ def backward(module, params, sv, dsr, need_dx=False):
             ops.wgrad_c3(dz1, sv["x3"], grads["conv1.0.weight"], 1)
         else:
             ops.conv_wgrad(sv["x3"], dz1, grads["conv1.0.weight"], 9, 1)
+    wg.run()
     ops.join_side()
     dx = None
     if need_dx:

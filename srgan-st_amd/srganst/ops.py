@@ -612,3 +612,65 @@ def flat_grads(module, names, params):
     lst.append(flat)
     del lst[:-4]
     return views
+
+
+class WgradGroup:
+    """Collects weight-gradient jobs of identical shape and issues them as ONE launch (+ one grouped slab reduce).
+    The device job table and the slab are cached per (shape, count); pointers are refreshed only when they change
+    (never under hipGraph replay: all tensors are static there)."""
+    _cache = {}
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0, in_act=ACT_NONE):
+        self.jobs.append((x, dy, dw_out, ksize, stride, in_scale, in_shift, in_slope, float(in_slope_const), int(in_act)))
+
+    def run(self):
+        import struct
+        if not self.jobs:
+            return
+        groups = {}
+        for j in self.jobs:
+            x, dy, dw, k, s = j[:5]
+            groups.setdefault((tuple(x.shape), tuple(dy.shape), k, s), []).append(j)
+        for (xs, dys, k, s), js in groups.items():
+            B, H, W, cin = xs
+            cout = dys[-1]
+            if len(js) == 1:
+                x, dy, dw, k, s, sc, sh, sl, slc, act = js[0]
+                conv_wgrad(x, dy, dw, k, s, in_scale=sc, in_shift=sh, in_slope=sl, in_slope_const=slc, in_act=act)
+                continue
+            dev = js[0][0].device
+            nch = _abi.lib().sst_conv_wgrad_chunks(B, dys[1], dys[2], cin, cout, k)
+            per = nch * k * k * cout * cin
+            key = (dev, xs, dys, k, s, len(js))
+            ent = WgradGroup._cache.get(key)
+            if ent is None:
+                ent = {"slab": torch.empty(len(js) * per, device=dev, dtype=torch.float32), "table": None, "ptrs": None}
+                WgradGroup._cache[key] = ent
+            slab = ent["slab"]
+            rows = []
+            for i, (x, dy, dw, _, _, sc, sh, sl, slc, act) in enumerate(js):
+                bits = struct.unpack("<q", struct.pack("<fi", slc, act))[0]
+                rows.append([x.data_ptr(), dy.data_ptr(), slab.data_ptr() + 4 * i * per, dw.data_ptr(), sc.data_ptr() if sc is not None else 0,
+                             sh.data_ptr() if sh is not None else 0, sl.data_ptr() if sl is not None else 0, bits])
+            if ent["table"] is None:
+                ent["table"] = torch.empty(len(js) * 8, device=dev, dtype=torch.int64)
+            if ent["ptrs"] != rows or torch.cuda.is_current_stream_capturing():
+                # (re)write the table with a kernel that carries the words as arguments: legal under graph capture, and the
+                # captured node then belongs to the graph (replays rewrite the same static pointers)
+                ent["ptrs"] = rows
+                import ctypes
+                flatw = [w for r in rows for w in r]
+                arr = (ctypes.c_longlong * len(flatw))(*flatw)
+                check(_abi.lib().sst_fill_table(ptr(ent["table"]), arr, len(flatw), stream_ptr()), "sst_fill_table")
+            e0 = _prof_begin()
+            args = (ptr(ent["table"]), len(js), B, H, W, cin, cout, s, k, 0)
+            check(_abi.lib().sst_conv_wgrad_grouped(*args, stream_ptr()), "sst_conv_wgrad_grouped")
+            flops = 2.0 * B * dys[1] * dys[2] * cout * cin * k * k * len(js)
+            _prof_end(e0, "conv_wgrad_kernel(grouped)+reduce", flops)
+            table = ent["table"]
+            _trace("conv_wgrad_kernel(grouped)+wgrad_reduce_kernel", flops,
+                   lambda args=args: _abi.lib().sst_conv_wgrad_grouped(*args, stream_ptr()), js, slab, table)
+        self.jobs = []
