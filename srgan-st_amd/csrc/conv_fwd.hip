@@ -185,21 +185,22 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
     }
     __syncthreads();
 
-#define SST_CHUNK(BUSE, BLOAD)                                                                         \
+#define SST_CHUNK(ACUR, ANEXT, BUSE, BLOAD)                                                            \
     {                                                                                                  \
-      const f32x4 av = a_load();                                                                       \
+      ANEXT = a_load();          /* next chunk's A fragment: its LDS latency hides behind these MFMAs */ \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], BUSE[j], acc, 0, 0, 0);                    \
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ACUR[j], BUSE[j], acc, 0, 0, 0);                  \
       BLOAD = pf_load();                                                                               \
     }
     if (nmine > 0 && !(a.dbg & 2)) {
+      f32x4 a0 = a_load(), a1;
       for (int c = 0; c < nmine; c += 6) {
-        SST_CHUNK(A0, B0)
-        SST_CHUNK(A1, B1)
-        SST_CHUNK(A2, B2)
-        SST_CHUNK(B0, A0)
-        SST_CHUNK(B1, A1)
-        SST_CHUNK(B2, A2)
+        SST_CHUNK(a0, a1, A0, B0)
+        SST_CHUNK(a1, a0, A1, B1)
+        SST_CHUNK(a0, a1, A2, B2)
+        SST_CHUNK(a1, a0, B0, A0)
+        SST_CHUNK(a0, a1, B1, A1)
+        SST_CHUNK(a1, a0, B2, A2)
       }
     }
 #undef SST_CHUNK
