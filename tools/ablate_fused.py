@@ -41,3 +41,7 @@ m, r = v(), v()
 dg, db, ds = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(1, device="cuda")
 _, _, pt = ops.conv_dgrad_fused(x, y2, wd, C, 3, cA, cB, cC, epi_y=y2)
 print("finalize2 (288 partials)%.1f us" % timeit(lambda: ops.bwd_finalize(pt, 9216, m, r, cA, dg, db, ds)))
+_, _, st, cnt = ops.conv_fwd(x, wd, C, 3, 1, want_stats=True)
+gm, bt, rm, rv = v(), v(), torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+print("bn_finalize (288 tiles) %.1f us" % timeit(lambda: ops.bn_finalize(st, cnt, gm, bt, rm, rv)))
+print("bn_residual             %.1f us" % timeit(lambda: ops.bn_residual(x, sc, sh, y2)))
