@@ -42,21 +42,28 @@ int sst_st_loss_bwd(const float* sr, const float* gS, float* dsr, const float* s
  *         x*in_scale+in_shift while staging (the producer's BatchNorm-apply + activation, fused).
  * out_mode: 0 NHWC, 1 PixelShuffle(2) store (model.py:160), 2 NCHW + clamp(0,1) with pre-clamp copy
  *           (model.py:148-150), 3 inverse pixel-shuffle store.
- * stats: per-tile BatchNorm partials [sst_conv_mtiles][2][Cout] (sum, centred M2), stats_cnt [mtiles]. */
+ * stats: per-tile BatchNorm partials [sst_conv_stat_tiles][2][Cout] (sum, centred M2), stats_cnt [tiles].
+ * The packed buffer of a 3x3 conv with 64 inputs and Cout % 16 == 0 carries a second copy of the weights in the layout
+ * of the band kernel (csrc/conv_band.hip), which sst_conv_fwd / sst_conv_dgrad_* use for stride-1 NHWC stores when the
+ * image rows group into bands of 144 or 48 pixels (the SRResNet trunk shape, model.py:173,176,113). */
 int64_t sst_conv_packed_floats(int Cout, int Cin, int ksize);
 int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksize, int mode, void* stream);
 /* one launch for many tensors: jobs = device array of {const float* w; float* wp; int Cout, Cin, KK, mode;
  * long long total, block_begin;} (48 bytes each; each workgroup packs 1024 floats) */
 int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, void* stream);
 int sst_conv_mtiles(int B, int Ho, int Wo);
+/* first dimension of stats / stats_cnt / epi_partial written by the NHWC-store conv of this shape (input H x W):
+ * one tile per band when the band kernel takes the shape, else sst_conv_mtiles of the output size */
+int sst_conv_stat_tiles(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 long sst_debug_big_tile_launches(void);   /* test hook: launches of the 64x64-tile conv kernel so far */
+long sst_debug_band_launches(void);       /* test hook: launches of the band conv kernel so far */
 int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,
                  const float* in_scale, const float* in_shift, const float* in_slope,
                  float in_slope_const, int in_act, const float* residual, float* stats,
                  float* stats_cnt, int out_mode, int B, int H, int W, int Cin, int Cout, int ksize,
                  int stride, void* stream);
 /* stride-1 data-gradient (mode 1 weights) whose epilogue also emits the BatchNorm/activation BACKWARD partial sums of
- * its result g against the saved conv output epi_y: epi_partial [sst_conv_mtiles][3][Cout] = per-tile sums of
+ * its result g against the saved conv output epi_y: epi_partial [sst_conv_stat_tiles][3][Cout] = per-tile sums of
  * (gz, gz*epi_y, g*min(z,0)) - the layout sst_bwd_finalize consumes (replaces a separate sst_bwd_reduce pass). */
 int sst_conv_dgrad_bwdstats(const float* x, const float* wp, float* y, const float* residual, const float* epi_y,
                             const float* epi_scale, const float* epi_shift, const float* epi_slope,

@@ -1,0 +1,353 @@
+// 3x3 / stride 1 / pad 1 convolution with 64 input channels, NHWC, fp32 MFMA - "band" decomposition for the
+// SRResNet trunk shape (reference model.py:173,176 _ResidualConvBlock convs, model.py:113 conv2, and their
+// data-gradients incl. the fused BatchNorm-backward stage, see sst_conv_dgrad_fused).
+//
+// Why a second kernel: the trunk conv is small (B*24*24 = 9216 pixels x 64 channels at the bench size).  The general
+// kernel (conv_fwd.hip) cuts it into 576 tiles of 32 px x 32 ch, i.e. 2.25 workgroups per CU: a quarter of the CUs run
+// 3 tiles while the rest run 2, and every tile re-reads its 74 KB of weights from L2.  Here a workgroup owns a BAND of
+// R full image rows (R*W a multiple of 16) x 16 output channels:
+//   * v_mfma_f32_16x16x4_f32 with M = 16 output channels (A = weights), N = 16 pixels (B = activations), K = 4 inputs;
+//     the band is NB = R*W/16 pixel blocks = NB accumulators per wave;
+//   * the 4 waves split K by INPUT CHANNEL (wave w owns channels 16w..16w+15 of all 9 taps), so each wave stages its own
+//     channel slice of the patch into its own LDS region and needs no workgroup barrier before the K loop;
+//   * per tap a wave needs ONE 16-B weight load per lane (9 per kernel, all issued before staging) and one
+//     ds_read_b128 per pixel block, which feeds 4 MFMAs (the 4 k-steps take channels {s, 4+s, 8+s, 12+s});
+//   * R = 6 at 24x24 (R = 3 at 48x48) gives B*4 bands x 4 channel groups = 256 workgroups for B = 16: one per CU, every
+//     SIMD runs exactly 324 MFMAs.
+// The K partials of the 4 waves are summed through LDS; the epilogue (bias, residual, BatchNorm statistics, backward
+// partials) matches conv_epilogue.h with one statistics tile per band.
+#include "conv_common.h"
+#include "conv_epilogue.h"
+#include <cstdlib>
+
+int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st);
+int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+
+namespace {
+
+constexpr int PSTR = 20;   // LDS floats per patch pixel of one wave's 16-channel slice (16 + 4 pad: conflict-free b128 reads)
+
+template <int NB>
+__global__ __launch_bounds__(CONV_NT) void conv_band_kernel(Conv3Args a, int R, int nbands) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float sstat[4][3][16];
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int W = a.W, PW = W + 2, npatch = (R + 2) * PW;
+  const int mt = blockIdx.x;
+  const int b = mt / nbands, y0 = (mt - b * nbands) * R;
+  const int g = blockIdx.y;                     // group of 16 output channels
+  float* P = lds + wave * npatch * PSTR;        // this wave's patch slice
+
+  // ---- weights of this (channel group, wave): 9 x 16 B per lane, in flight while the patch is staged
+  f32x4 wv[9];
+  {
+    const float* wb = a.wp + packed_floats_base(a.Cout, 64, 9) + ((size_t)g * 9 * 4 + wave) * 256 + lane * 4;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(wb + t * 4 * 256);
+  }
+
+  // ---- stage this wave's 16-channel slice of the (R+2) x (W+2) patch; padding stays zero
+  {
+    const int q4 = (lane & 3) * 4, c = wave * 16 + q4;
+    const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    f32x4 kA = {1.f, 1.f, 1.f, 1.f}, kB = {0.f, 0.f, 0.f, 0.f}, kC = {0.f, 0.f, 0.f, 0.f};
+    if (a.in_scale) {
+      sc = *reinterpret_cast<const f32x4*>(a.in_scale + c);
+      sh = *reinterpret_cast<const f32x4*>(a.in_shift + c);
+    }
+    if (a.in_cA) {
+      kA = *reinterpret_cast<const f32x4*>(a.in_cA + c);
+      kB = *reinterpret_cast<const f32x4*>(a.in_cB + c);
+      kC = *reinterpret_cast<const f32x4*>(a.in_cC + c);
+    }
+    const float* xb = a.x + (size_t)b * a.H * W * 64 + c;
+    const float* x2b = a.in2 ? a.in2 + (size_t)b * a.H * W * 64 + c : nullptr;
+    float* sob = (a.side_out && g == 0) ? a.side_out + (size_t)b * a.H * W * 64 + c : nullptr;
+    // patch pixel p = it*16 + lane/4  ->  (py, px), advanced incrementally (no per-iteration division)
+    int p = lane >> 2;
+    int py = p / PW, px = p - py * PW;
+    constexpr int UN = 4;
+    const int nit = (a.dbg & 1) ? 0 : (npatch + 15) / 16;
+    for (int it0 = 0; it0 < nit; it0 += UN) {
+      f32x4 v[UN], yv[UN];
+      int off[UN], lp[UN];
+      bool ok[UN], own[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int iy = y0 - 1 + py, ix = px - 1;
+        ok[u] = (it0 + u < nit) && p < npatch && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)W;
+        own[u] = py >= 1 && py <= R;
+        lp[u] = p < npatch ? p : -1;
+        off[u] = (iy * W + ix) * 64;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        yv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[u]) {
+          v[u] = *reinterpret_cast<const f32x4*>(xb + off[u]);
+          if (x2b) yv[u] = *reinterpret_cast<const f32x4*>(x2b + off[u]);
+        }
+        p += 16;
+        px += 16;
+        if (px >= PW) { px -= PW; ++py; }
+        if (px >= PW) { px -= PW; ++py; }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (lp[u] < 0 || it0 + u >= nit) continue;
+        f32x4 t = v[u];
+        if (ok[u]) {
+          if (x2b) {                        // fused BatchNorm-backward apply (see Conv3Args)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float gz = t[j];
+              if (a.in_act == ACT_SLOPE) {
+                const float z = fmaf(yv[u][j], sc[j], sh[j]);
+                gz = z > 0.f ? gz : gz * slope;
+              }
+              t[j] = a.in_cA ? fmaf(kA[j], gz, fmaf(kB[j], yv[u][j], kC[j])) : gz;
+            }
+            if (sob && own[u]) *reinterpret_cast<f32x4*>(sob + off[u]) = t;
+          } else {
+            if (a.in_scale) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) t[j] = fmaf(t[j], sc[j], sh[j]);
+            }
+            if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) t[j] = t[j] > 0.f ? t[j] : t[j] * slope;
+            }
+          }
+        }
+        *reinterpret_cast<f32x4*>(&P[lp[u] * PSTR + q4]) = t;
+      }
+    }
+  }
+
+  // ---- per-lane LDS offsets of the NB pixel blocks: pixel n = blk*16 + lane%16 of the band -> patch (r, c) top-left
+  const int lp16 = lane & 15, lj = lane >> 4;
+  int boff[NB];
+  {
+    int r = lp16 / W, c = lp16 - r * W;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      boff[k] = (r * PW + c) * PSTR + 4 * lj;
+      c += 16;
+      if (c >= W) { c -= W; ++r; }
+      if (c >= W) { c -= W; ++r; }
+    }
+  }
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (!(a.dbg & 2)) {
+    // the patch slice is wave-private: only this wave's own LDS writes have to land (no workgroup barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x4 bv[2][NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) bv[0][k] = *reinterpret_cast<const f32x4*>(&P[boff[k]]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t + 1 < 9) {
+        const int toff = (((t + 1) / 3) * PW + (t + 1) % 3) * PSTR;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) bv[(t + 1) & 1][k] = *reinterpret_cast<const f32x4*>(&P[boff[k] + toff]);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][s], bv[t & 1][k][s], acc[k], 0, 0, 0);
+    }
+  }
+
+  if (a.dbg & 4) {
+    if (acc[0][0] == 12345.f) a.y[0] = acc[0][0];
+    return;
+  }
+
+  // ---- sum the 4 waves' K partials through LDS (overlays the patches): red[wave][blk][lane] (16 B each)
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NB; ++k) *reinterpret_cast<f32x4*>(&lds[((wave * NB + k) * 64 + lane) * 4]) = acc[k];
+  __syncthreads();
+
+  // wave w finalises blocks w, w+4, w+8: lane -> pixel blk*16 + lane%16, output channels 16g + 4*(lane/16) .. +3
+  constexpr int MYB = (NB + 3) / 4;
+  const int npx = R * W;
+  const int c0 = g * 16 + 4 * lj;
+  f32x4 v[MYB];
+  size_t obase[MYB];
+  bool have[MYB];
+#pragma unroll
+  for (int i = 0; i < MYB; ++i) {
+    const int blk = wave + 4 * i;
+    have[i] = blk < NB;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    obase[i] = 0;
+    if (have[i]) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(&lds[((0 * NB + blk) * 64 + lane) * 4]);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(&lds[((w * NB + blk) * 64 + lane) * 4]);
+        s += t;
+      }
+      if (a.bias) s += *reinterpret_cast<const f32x4*>(a.bias + c0);
+      const int n = blk * 16 + lp16;
+      const int r = n / W, c = n - r * W;
+      obase[i] = (((size_t)b * a.H + y0 + r) * W + c) * a.Cout + c0;
+      if (a.residual) s += *reinterpret_cast<const f32x4*>(a.residual + obase[i]);
+      *reinterpret_cast<f32x4*>(a.y + obase[i]) = s;
+      v[i] = s;
+    }
+  }
+
+  auto reduce16 = [](float t) {   // over the 16 lanes that share lane/16 (same output channels)
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 4, 64);
+    t += __shfl_xor(t, 8, 64);
+    return t;
+  };
+
+  if (a.stats) {
+    // per-band (sum, centred M2) per output channel
+    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MYB; ++i) s1 += v[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s1[j] = reduce16(s1[j]);
+    if (lp16 == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sstat[wave][0][4 * lj + j] = s1[j];
+    }
+    __syncthreads();
+    f32x4 m2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = 4 * lj + j;
+      const float mean = (sstat[0][0][ch] + sstat[1][0][ch] + sstat[2][0][ch] + sstat[3][0][ch]) / (float)npx;
+#pragma unroll
+      for (int i = 0; i < MYB; ++i) {
+        const float d = have[i] ? v[i][j] - mean : 0.f;
+        m2[j] = fmaf(d, d, m2[j]);
+      }
+      m2[j] = reduce16(m2[j]);
+    }
+    if (lp16 == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sstat[wave][1][4 * lj + j] = m2[j];
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float* st = a.stats + (size_t)mt * 2 * a.Cout + g * 16 + tid;
+      st[0] = sstat[0][0][tid] + sstat[1][0][tid] + sstat[2][0][tid] + sstat[3][0][tid];
+      st[a.Cout] = sstat[0][1][tid] + sstat[1][1][tid] + sstat[2][1][tid] + sstat[3][1][tid];
+      if (tid == 0 && g == 0) a.stats_cnt[mt] = (float)npx;
+    }
+  }
+
+  if (a.epi_partial) {
+    // backward partials of the stored g against epi_y (see Conv3Args): sums of (gz, gz*y, g*min(z,0)) over the band
+    const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
+    f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
+    if (a.epi_scale) {
+      esc = *reinterpret_cast<const f32x4*>(a.epi_scale + c0);
+      esh = *reinterpret_cast<const f32x4*>(a.epi_shift + c0);
+    }
+    f32x4 q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MYB; ++i) {
+      if (!have[i]) continue;
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(a.epi_y + obase[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gq = v[i][j];
+        const float z = a.epi_scale ? fmaf(yv[j], esc[j], esh[j]) : yv[j];
+        float gz = gq, q2 = 0.f;
+        if (a.epi_act) {
+          q2 = gq * fminf(z, 0.f);
+          gz = z > 0.f ? gq : gq * eslope;
+        }
+        q[0][j] += gz;
+        q[1][j] = fmaf(gz, yv[j], q[1][j]);
+        q[2][j] += q2;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[k][j] = reduce16(q[k][j]);
+    __syncthreads();
+    if (lp16 == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sstat[wave][k][4 * lj + j] = q[k][j];
+    }
+    __syncthreads();
+    if (tid < 48) {
+      const int k = tid >> 4, c = tid & 15;
+      a.epi_partial[((size_t)mt * 3 + k) * a.Cout + g * 16 + c] = sstat[0][k][c] + sstat[1][k][c] + sstat[2][k][c] + sstat[3][k][c];
+    }
+  }
+}
+
+inline size_t band_lds_bytes(int R, int W, int NB) {
+  const size_t patch = (size_t)4 * (R + 2) * (W + 2) * PSTR, red = (size_t)4 * NB * 256;
+  return sizeof(float) * (patch > red ? patch : red);
+}
+
+}  // namespace
+
+// Rows per band for this conv shape, or 0 when the band kernel does not apply (the caller then uses conv_fwd_kernel).
+// Pure function of the shape (plus the SST_CONV_BAND dev override), so that sst_conv_stat_tiles can predict the dispatch.
+int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  if (ksize != 3 || stride != 1 || !band_eligible(Cout, Cin, 9) || W < 8) return 0;
+  int want = 3;   // measured on the bench step: 768 bands of 48 px (3 workgroups per CU) beat 256 bands of 144 px by 3.6 %
+  if (const char* e = getenv("SST_CONV_BAND")) {
+    want = atoi(e);
+    if (want == 0) return 0;
+  }
+  // NB = R*W/16 must be one of the compiled block counts; prefer `want`, then the other
+  const int cand[2] = {want == 9 ? 9 : 3, want == 9 ? 3 : 9};
+  for (int k = 0; k < 2; ++k) {
+    const int px = cand[k] * 16;
+    if (px % W) continue;
+    const int R = px / W;
+    if (R <= 0 || H % R) continue;
+    if (band_lds_bytes(R, W, cand[k]) > 128 * 1024) continue;
+    return R;
+  }
+  return 0;
+}
+
+static long g_band_launches = 0;
+SST_API long sst_debug_band_launches(void) { return g_band_launches; }   // test hook: how often the band kernel was chosen
+
+int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st) {
+  ++g_band_launches;
+  const int NB = R * a.W / 16, nbands = a.H / R;
+  dim3 grid((unsigned)(a.B * nbands), a.Cout / 16);
+  const size_t lds = band_lds_bytes(R, a.W, NB);
+  static bool big_lds_enabled = false;     // > 64 KB of dynamic LDS needs the opt-in (gfx950 has 160 KB per CU)
+  if (!big_lds_enabled) {
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band_kernel<9>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band_kernel<3>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e1 != hipSuccess || e2 != hipSuccess) return sst_set_error(SST_ERR_HIP, "conv_band: cannot raise the LDS limit");
+    big_lds_enabled = true;
+  }
+  if (NB == 9)
+    conv_band_kernel<9><<<grid, CONV_NT, lds, st>>>(a, R, nbands);
+  else if (NB == 3)
+    conv_band_kernel<3><<<grid, CONV_NT, lds, st>>>(a, R, nbands);
+  else
+    return sst_set_error(SST_ERR_UNSUPPORTED, "conv_band: NB=%d not built", NB);
+  SST_LAUNCH_CHECK("conv_band_kernel");
+  return SST_OK;
+}

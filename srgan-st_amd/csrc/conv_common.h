@@ -23,6 +23,18 @@ __host__ __device__ inline int64_t packed_index(int o, int i, int tap, int ncb, 
          (i & 3);
 }
 constexpr int PACK_PAD = 8 * 256;   // the K loop prefetches up to 4 chunks (1 KiB each) past a block: keep them in-bounds
-__host__ __device__ inline int64_t packed_floats(int cout, int cin, int kk) {
+__host__ __device__ inline int64_t packed_floats_base(int cout, int cin, int kk) {
   return (int64_t)((cout + 31) / 32) * ((cin + 63) / 64) * kk * 8 * 256 + PACK_PAD;
+}
+
+// Second section of the packed buffer, present when band_eligible(): the same weights in the layout of the band kernel
+// (conv_band.hip: v_mfma_f32_16x16x4_f32 with M = 16 outputs, K = 4 inputs; wave w owns inputs 16w..16w+15 and reads its
+// A fragments for the 4 k-steps of one tap as ONE 16-B load per lane, 1 KiB per wave):
+//   band_index(o, i, tap) = (((o/16 * 9 + tap) * 4 + i/16) * 64 + (o%16) + 16*((i%16)/4)) * 4 + i%4
+__host__ __device__ inline bool band_eligible(int cout, int cin, int kk) { return kk == 9 && cin == 64 && (cout & 15) == 0; }
+__host__ __device__ inline int64_t band_index(int o, int i, int tap) {
+  return ((((int64_t)(o >> 4) * 9 + tap) * 4 + (i >> 4)) * 64 + (o & 15) + 16 * ((i & 15) >> 2)) * 4 + (i & 3);
+}
+__host__ __device__ inline int64_t packed_floats(int cout, int cin, int kk) {
+  return packed_floats_base(cout, cin, kk) + (band_eligible(cout, cin, kk) ? (int64_t)cout * cin * 9 : 0);
 }

@@ -24,6 +24,9 @@
 
 // 64x64-tile variant (conv_fwd2.hip)
 int sst_launch_conv_fwd2(const Conv3Args& a, int stride, hipStream_t st);
+// band kernel for the 64-input-channel trunk shape (conv_band.hip)
+int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st);
+int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 
 namespace {
 
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
     const int cbeg = (nchunks * wave) >> 2, cend = (nchunks * (wave + 1)) >> 2;
     const int nmine = cend - cbeg;
     const float* wblk = a.wp + ((size_t)(nf * ncb + cb) * KK * 8) * 256 + lane * 4;
-    const float* wzero = a.wp + (packed_floats(a.Cout, a.Cin, KK) - PACK_PAD) + lane * 4;
+    const float* wzero = a.wp + (packed_floats_base(a.Cout, a.Cin, KK) - PACK_PAD) + lane * 4;
     // cursors (wave-uniform scalars): A = chunk being multiplied, P = chunk being prefetched
     int a_ks, a_dx, a_off, a_i = 0;
     int p_ks, p_off, p_i = 0;
@@ -220,7 +223,15 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
                                  int mode, int64_t total) {
   const int O = mode ? Cin : Cout, I = mode ? Cout : Cin;
   const int ncb = (I + 63) / 64;
+  const int64_t base = packed_floats_base(O, I, KK);
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx >= base) {   // band-kernel section (conv_common.h: band_index)
+      const int64_t q = idx - base;
+      const int l = (q >> 2) & 63, tap = (q >> 10) % 9;
+      const int o = (int)((q >> 10) / 9) * 16 + (l & 15), i = ((q >> 8) & 3) * 16 + (l >> 4) * 4 + (q & 3);
+      wp[idx] = mode == 0 ? w[((size_t)o * Cin + i) * KK + tap] : w[((size_t)i * Cin + o) * KK + (KK - 1 - tap)];
+      continue;
+    }
     // decode packed index
     const int j = idx & 3;
     const int l = (idx >> 2) & 63;
@@ -261,10 +272,19 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
   const int O = jb.mode ? jb.Cin : jb.Cout, I = jb.mode ? jb.Cout : jb.Cin;
   const int ncb = (I + 63) / 64;
   const long long base = ((long long)blockIdx.x - jb.block_begin) * 1024;
+  const long long bbase = packed_floats_base(O, I, jb.KK);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const long long idx = base + u * 256 + threadIdx.x;
     if (idx >= jb.total) break;
+    if (idx >= bbase) {   // band-kernel section
+      const long long q = idx - bbase;
+      const int l = (q >> 2) & 63, tap = (q >> 10) % 9;
+      const int o = (int)((q >> 10) / 9) * 16 + (l & 15), i = ((q >> 8) & 3) * 16 + (l >> 4) * 4 + (q & 3);
+      jb.wp[idx] = jb.mode == 0 ? jb.w[((size_t)o * jb.Cin + i) * jb.KK + tap]
+                                : jb.w[((size_t)i * jb.Cin + o) * jb.KK + (jb.KK - 1 - tap)];
+      continue;
+    }
     const int j = idx & 3, l = (idx >> 2) & 63, ks = (idx >> 8) & 7;
     long long rest = idx >> 11;
     const int tap = rest % jb.KK;
@@ -343,6 +363,15 @@ SST_API int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, v
 
 SST_API int sst_conv_mtiles(int B, int Ho, int Wo) { return B * ((Ho + THO - 1) / THO) * ((Wo + TWO - 1) / TWO); }
 
+// Number of statistics tiles (first dimension of stats / stats_cnt / epi_partial) the NHWC-store conv of this shape
+// writes: one per band when the band kernel (conv_band.hip) takes the shape, else sst_conv_mtiles of the output.
+SST_API int sst_conv_stat_tiles(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  const int R = sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride);
+  if (R) return B * (H / R);
+  const int p = ksize / 2;
+  return sst_conv_mtiles(B, (H + 2 * p - ksize) / stride + 1, (W + 2 * p - ksize) / stride + 1);
+}
+
 // y = conv(act(x*in_scale+in_shift), w) (+bias) (+residual), stored per out_mode; optional BN partial stats.
 static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre, const float* bias, const float* in_scale,
                          const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
@@ -384,6 +413,10 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   hipStream_t st = sst_stream(stream);
   const size_t extra_lds = (size_t)(dbg_bits >> 4) * 1024;   // dev knob: pad LDS to cap workgroups per CU
   a.dbg = dbg_bits & 15;
+  if (out_mode == OUT_NHWC && !(dbg_bits & 8)) {
+    const int R = sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride);
+    if (R) return sst_launch_conv_band(a, R, st);
+  }
   if (dbg_bits == 0 && use_big_tiles(a, ksize)) return sst_launch_conv_fwd2(a, stride, st);
   if (ksize == 3 && stride == 1)
     conv_fwd_kernel<3, 1><<<grid, CONV_NT, extra_lds, st>>>(a);

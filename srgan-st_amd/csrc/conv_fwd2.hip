@@ -50,7 +50,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd2_kernel(Conv3Args a) {
     if (cb) __syncthreads();
     const int cbeg = (nchunks * wave) >> 2, cend = (nchunks * (wave + 1)) >> 2;
     const int nmine = cend - cbeg;
-    const float* wzero = a.wp + (packed_floats(a.Cout, a.Cin, KK) - PACK_PAD) + lane * 4;
+    const float* wzero = a.wp + (packed_floats_base(a.Cout, a.Cin, KK) - PACK_PAD) + lane * 4;
     const float* wblk0 = a.wp + ((size_t)(nf0 * ncb + cb) * KK * 8) * 256 + lane * 4;
     const float* wblk1 = (nf0 + 1 < nfblocks) ? a.wp + ((size_t)((nf0 + 1) * ncb + cb) * KK * 8) * 256 + lane * 4 : nullptr;
     int a_ks, a_dx, a_off, a_i = 0;

@@ -28,7 +28,9 @@ SIGNATURES = {
     "sst_bwd_reduce_finalize": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P, c_float, P, P, P, P, P, P, P, P,
                                         P, c_int, P]),
     "sst_debug_big_tile_launches": (ctypes.c_long, []),
+    "sst_debug_band_launches": (ctypes.c_long, []),
     "sst_conv_mtiles": (c_int, [c_int, c_int, c_int]),
+    "sst_conv_stat_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_dgrad_bwdstats": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

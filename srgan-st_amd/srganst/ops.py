@@ -83,7 +83,7 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
     y_pre = torch.empty_like(y) if want_pre else None
     stats = cnt = None
     if want_stats:
-        mt = _abi.lib().sst_conv_mtiles(B, ho, wo)
+        mt = _abi.lib().sst_conv_stat_tiles(B, H, W, cin, cout, ksize, stride)
         stats = _f32(mt, 2, cout, like=x)
         cnt = _f32(mt, like=x)
     e0 = _prof_begin()
@@ -550,7 +550,7 @@ def conv_dgrad_bwdstats(dy, wd, cout, ksize, epi_y, residual=None, epi_scale=Non
     against epi_y ([mtiles,3,cout], the layout bwd_finalize consumes)."""
     B, H, W, cin = dy.shape
     g = _f32(B, H, W, cout, like=dy)
-    mt = _abi.lib().sst_conv_mtiles(B, H, W)
+    mt = _abi.lib().sst_conv_stat_tiles(B, H, W, cin, cout, ksize, 1)
     partial = _f32(mt, 3, cout, like=dy)
     args = (ptr(dy), ptr(wd), ptr(g), ptr(residual), ptr(epi_y), ptr(epi_scale), ptr(epi_shift), ptr(epi_slope),
             float(epi_slope_const), int(epi_act), ptr(partial), B, H, W, cin, cout, ksize)
@@ -582,7 +582,7 @@ def conv_dgrad_fused(g, y2, wd, cout, ksize, cA=None, cB=None, cC=None, in_scale
     dy = torch.empty_like(g)
     partial = None
     if epi_y is not None:
-        partial = _f32(_abi.lib().sst_conv_mtiles(B, H, W), 3, cout, like=g)
+        partial = _f32(_abi.lib().sst_conv_stat_tiles(B, H, W, cin, cout, ksize, 1), 3, cout, like=g)
     args = (ptr(g), ptr(y2), ptr(cA), ptr(cB), ptr(cC), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const),
             int(in_act), ptr(dy), ptr(wd), ptr(out), ptr(residual), ptr(epi_y), ptr(epi_scale), ptr(epi_shift), ptr(epi_slope),
             float(epi_slope_const), int(epi_act), ptr(partial), B, H, W, cin, cout, ksize)

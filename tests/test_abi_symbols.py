@@ -39,4 +39,6 @@ def test_library_identity_and_error_channel():
     n = ctypes.c_int64()
     assert lib.sst_st_loss_workspace(16, 96, 96, ctypes.byref(n)) == 0 and n.value == 16 * 9
     assert lib.sst_conv_mtiles(16, 24, 24) == 288
-    assert lib.sst_conv_packed_floats(64, 64, 3) == 2 * 1 * 9 * 8 * 256 + 2048
+    assert lib.sst_conv_packed_floats(64, 64, 3) == 2 * 1 * 9 * 8 * 256 + 2048 + 64 * 64 * 9   # + band-kernel copy
+    assert lib.sst_conv_packed_floats(128, 128, 3) == 4 * 2 * 9 * 8 * 256 + 2048
+    assert lib.sst_conv_stat_tiles(16, 24, 24, 64, 64, 3, 1) == 192 and lib.sst_conv_stat_tiles(16, 24, 24, 64, 64, 3, 2) == 96

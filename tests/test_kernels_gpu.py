@@ -301,3 +301,74 @@ def test_conv_big_tile_kernel(ops, case, monkeypatch):
         dx = ops.conv_s2_dgrad(nhwc(dy).cuda(), ops.pack_conv_s2_dgrad(w.cuda()), H, W, Cin)
         assert rel_err(nchw(dx.cpu()), xg.grad) < TOL
     assert _abi.lib().sst_debug_big_tile_launches() >= n_before + 2      # the 64x64 kernel really ran
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, "9"), (2, 24, 24, 64, "3"), (1, 48, 48, 64, "9"), (1, 48, 48, 32, "3"),
+                                  (3, 12, 12, 64, "9"), (1, 12, 12, 16, "3"), (2, 18, 8, 64, "9")])
+def test_conv_band_kernel(ops, case, monkeypatch):
+    """The band kernel (csrc/conv_band.hip; NB = 9 or 3 pixel blocks per band forced with SST_CONV_BAND) against fp64
+    conv2d and against the general kernel: forward with prologue + bias + residual + BatchNorm statistics, the plain
+    data-gradient with backward partials, and the fused BatchNorm-backward stage (apply on load, dy side output)."""
+    B, H, W, Cout, nb = case
+    Cin = 64
+    from srganst import _abi
+    monkeypatch.setenv("SST_CONV_BAND", nb)
+    assert _abi.lib().sst_conv_stat_tiles(B, H, W, Cin, Cout, 3, 1) == B * H * W // (16 * int(nb))
+    n_before = _abi.lib().sst_debug_band_launches()
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24.0
+    bias = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    slope = torch.tensor([0.25])
+    xin = F.prelu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), slope.double())
+    res = torch.randn(B, Cout, H, W, generator=g)
+    full = F.conv2d(xin, w.double(), bias.double(), 1, 1) + res.double()
+    wp = ops.pack_conv(w.cuda())
+    y, _, stats, cnt = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, 3, 1, bias=bias.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(),
+                                    in_slope=slope.cuda(), in_act=ops.ACT_SLOPE, residual=nhwc(res).cuda(), want_stats=True)
+    assert rel_err(nchw(y.cpu()), full) < TOL
+    assert stats.shape[0] == B * H * W // (16 * int(nb)) and float(cnt.sum()) == B * H * W
+    mean, rstd, _, _ = ops.bn_finalize(stats, cnt, torch.ones(Cout).cuda(), torch.zeros(Cout).cuda())
+    assert rel_err(mean.cpu(), full.mean(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(rstd.cpu(), 1 / torch.sqrt(full.var(dim=(0, 2, 3), unbiased=False) + 1e-5)) < 1e-4
+
+    # data-gradient of a (Cout -> 64)... roles: the conv below maps 64 "dy" channels to Cout "dx" channels
+    wt = torch.randn(Cin, Cout, 3, 3, generator=g) / 24.0            # a conv Cout -> 64 whose dgrad has 64 inputs
+    dy = torch.randn(B, Cin, H, W, generator=g)
+    gref = torch.nn.grad.conv2d_input((B, Cout, H, W), wt.double(), dy.double(), 1, 1)
+    ysave = torch.randn(B, Cout, H, W, generator=g)
+    esc, esh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    wd = ops.pack_conv(wt.cuda(), 1)
+    gd, part = ops.conv_dgrad_bwdstats(nhwc(dy).cuda(), wd, Cout, 3, nhwc(ysave).cuda(), residual=nhwc(res).cuda(),
+                                       epi_scale=esc.cuda(), epi_shift=esh.cuda(), epi_slope=slope.cuda(), epi_act=1)
+    gfull = gref + res.double()
+    assert rel_err(nchw(gd.cpu()), gfull) < TOL
+    z = ysave.double() * esc.double().view(1, -1, 1, 1) + esh.double().view(1, -1, 1, 1)
+    gz = torch.where(z > 0, gfull, gfull * 0.25)
+    tot = part.sum(dim=0).cpu()
+    assert part.shape[0] == stats.shape[0]
+    assert rel_err(tot[0], gz.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(tot[1], (gz * ysave.double()).sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(tot[2], (gfull * z.clamp(max=0)).sum(dim=(0, 2, 3))) < 1e-4
+
+    # fused BatchNorm-backward stage: must equal the general kernel bit for bit in dy, and to rounding in the conv
+    y2 = torch.randn(B, Cin, H, W, generator=g)
+    cA, cB, cC = (torch.randn(Cin, generator=g) for _ in range(3))
+    args = dict(cA=cA.cuda(), cB=cB.cuda(), cC=cC.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(), in_slope=slope.cuda(), in_act=1,
+                residual=nhwc(res).cuda(), epi_y=nhwc(ysave).cuda(), epi_scale=esc.cuda(), epi_shift=esh.cuda(),
+                epi_slope=slope.cuda(), epi_act=1)
+    out_b, dy_b, part_b = ops.conv_dgrad_fused(nhwc(dy).cuda(), nhwc(y2).cuda(), wd, Cout, 3, **args)
+    assert _abi.lib().sst_debug_band_launches() == n_before + 3           # the band kernel really ran, every time
+    monkeypatch.setenv("SST_CONV_BAND", "0")
+    out_g, dy_g, part_g = ops.conv_dgrad_fused(nhwc(dy).cuda(), nhwc(y2).cuda(), wd, Cout, 3, **args)
+    assert _abi.lib().sst_debug_band_launches() == n_before + 3
+    assert torch.equal(dy_b, dy_g)
+    assert rel_err(out_b.cpu(), out_g.cpu()) < TOL
+    assert rel_err(part_b.sum(dim=0).cpu(), part_g.sum(dim=0).cpu()) < 1e-4
+    z2 = y2.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    gz2 = torch.where(z2 > 0, dy.double(), dy.double() * 0.25)
+    dyr = cA.double().view(1, -1, 1, 1) * gz2 + cB.double().view(1, -1, 1, 1) * y2.double() + cC.double().view(1, -1, 1, 1)
+    assert rel_err(nchw(dy_b.cpu()), dyr) < TOL
+    oref = torch.nn.grad.conv2d_input((B, Cout, H, W), wt.double(), dyr, 1, 1) + res.double()
+    assert rel_err(nchw(out_b.cpu()), oref) < TOL
