@@ -333,7 +333,20 @@ SST_API int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, in
   a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
   const int64_t M = (int64_t)B * a.Ho * a.Wo;
   SST_REQUIRE(M < (1ll << 31), "sst_conv_wgrad_grouped: too many pixels");
-  const int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
+  // With many layers in one grid the chip is full without fine pixel chunks: aim at ~target workgroups in total
+  // (fewer, longer chunks = less slab traffic).  Never more chunks than the per-layer slab was sized for.
+  int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
+  {
+    int target = 2048;
+    if (const char* e = getenv("SST_WGRAD_GROUP_WGS")) target = atoi(e);
+    const int nblk = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    int want = (target + ksize * ksize * nblk * njobs - 1) / (ksize * ksize * nblk * njobs);
+    if (want < 1) want = 1;
+    if (target > 0 && want < nchunk) {
+      const int64_t cpx = ((M + want - 1) / want + SUB - 1) / SUB * SUB;
+      nchunk = (int)((M + cpx - 1) / cpx);
+    }
+  }
   a.nchunk = nchunk;
   a.chunk_px = (int)(((M + nchunk - 1) / nchunk + SUB - 1) / SUB * SUB);
   a.dbg = 0;
