@@ -57,6 +57,7 @@ int sst_conv_mtiles(int B, int Ho, int Wo);
 int sst_conv_stat_tiles(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 long sst_debug_big_tile_launches(void);   /* test hook: launches of the 64x64-tile conv kernel so far */
 long sst_debug_band_launches(void);       /* test hook: launches of the band conv kernel so far */
+long sst_debug_wgrad_band_launches(void); /* test hook: launches of the all-taps weight-gradient kernel so far */
 int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,
                  const float* in_scale, const float* in_shift, const float* in_slope,
                  float in_slope_const, int in_act, const float* residual, float* stats,
@@ -78,7 +79,10 @@ int sst_conv_dgrad_fused(const float* g, const float* y2, const float* cA, const
                          float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin, int Cout,
                          int ksize, void* stream);
 /* dW[Cout][Cin][k][k] (+)= sum_pixels X'(shifted) * dY ; slab = sst_conv_wgrad_chunks*k*k*Cout*Cin floats */
-int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int ksize);
+int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int ksize);   /* general (per-tap) kernel only */
+/* chunk count sst_conv_wgrad (njobs = 1) / sst_conv_wgrad_grouped (njobs layers) actually use; H, W = input size.
+ * 3x3 stride-1 layers with Cin, Cout multiples of 64 run the all-taps band kernel (csrc/conv_wgrad.hip). */
+int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs);
 int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
                    const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
                    int B, int H, int W, int Cin, int Cout, int stride, int ksize, int accumulate,

@@ -37,6 +37,7 @@ struct WgradArgs {
   int in_act;
   int B, H, W, Cin, Cout, Ho, Wo, stride, KS, pad;
   int chunk_px;            // pixels per chunk (multiple of SUB)
+  int R, bpc, nbands;      // band kernel: rows per band, bands per chunk, bands in the tensor (B*H/R)
   int dbg;                 // dev ablation bits from $SST_WGRAD_DBG (0 in production): 1 no global loads, 2 no MFMA, 4 no slab store
 };
 
@@ -207,6 +208,194 @@ __global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ---- "all taps" variant for 3x3 / stride 1 / pad 1 with Cin, Cout multiples of 64 (every trunk / up-sampler conv of the
+// generator, the stride-1 convs of the discriminator).  A workgroup owns a 64x64 (co,ci) block for ALL 9 taps: wave w keeps
+// 9 accumulators (one 32x32 block per tap, 144 AGPRs), so the dY tile and the X patch of a band of R image rows are staged
+// ONCE and feed 9 MFMAs per pixel pair - the kernel above stages both once per tap.  The workgroup walks `bpc` consecutive
+// bands, prefetching the next band into registers while the MFMAs of the current one run, and writes one slab tile per tap
+// at the end (same slab layout, same reduce kernel).
+constexpr int WB_XS = 10, WB_DS = 3;      // max register slots (16 B each) per thread for the X patch / dY tile of one band
+
+template <int XS>
+__global__ __launch_bounds__(CONV_NT, 2) void conv_wgrad_band_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  int chunk = blockIdx.x;
+  if (a.jobs) {
+    const int job = blockIdx.x / a.nchunk;
+    chunk = blockIdx.x - job * a.nchunk;
+    const WgJob jb = a.jobs[job];
+    a.x = jb.x; a.dy = jb.dy; a.slab = jb.slab; a.in_scale = jb.in_scale; a.in_shift = jb.in_shift;
+    a.in_slope = jb.in_slope; a.in_slope_const = jb.in_slope_const; a.in_act = jb.in_act;
+  }
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int R = a.R, W = a.W, PW = W + 2, H = a.H;
+  const int npx_x = (R + 2) * PW, npx_d = R * W;
+  float* sX = wlds;
+  float* sD = wlds + npx_x * WLD;
+  const int nci = a.Cin >> 6;
+  const int cob = blockIdx.y / nci, cib = blockIdx.y - cob * nci;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  const int wco = (wave & 1) * 32, wci = (wave >> 1) * 32;
+  const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
+  const int bands_per_img = H / R;
+  const int band_begin = chunk * a.bpc, band_end = min(a.nbands, band_begin + a.bpc);
+
+  // staging slots: q = tid + u*256 -> patch pixel q/16, channel quad q%16 (a thread's channel quad is fixed)
+  const int c4 = (tid & 15) * 4;
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.in_scale) {
+    sc4 = *reinterpret_cast<const f32x4*>(a.in_scale + ci0 + c4);
+    sh4 = *reinterpret_cast<const f32x4*>(a.in_shift + ci0 + c4);
+  }
+  // Slot validity: the halo columns are never valid; patch row 0 / R+1 fall outside the image for the first / last band of
+  // an image.  Three static bit masks over the slots replace per-slot row bookkeeping.
+  int xoff[XS];             // element offset of the slot's pixel relative to the band origin pixel (b, y0, 0)
+  unsigned m_col = 0, m_top = 0, m_bot = 0;
+#pragma unroll
+  for (int u = 0; u < XS; ++u) {
+    const int p = (tid + u * CONV_NT) >> 4;
+    const int py = p / PW, px = p - py * PW;
+    if (p < npx_x && px >= 1 && px <= W) m_col |= 1u << u;
+    if (py == 0) m_top |= 1u << u;
+    if (py == R + 1) m_bot |= 1u << u;
+    xoff[u] = ((py - 1) * W + (px - 1)) * a.Cin;
+  }
+  f32x4 rx[XS], rd[WB_DS];
+  unsigned rvalid = 0;
+  auto stage_load = [&](int band) {
+    const int b = band / bands_per_img, y0 = (band - b * bands_per_img) * R;
+    const float* xb = a.x + ((size_t)(b * H + y0) * W) * a.Cin + ci0 + c4;
+    const float* db = a.dy + ((size_t)(b * H + y0) * W) * a.Cout + co0 + c4;
+    rvalid = m_col & ~(y0 == 0 ? m_top : 0u) & ~(y0 + R == H ? m_bot : 0u);
+#pragma unroll
+    for (int u = 0; u < XS; ++u) {
+      const bool ok = (rvalid >> u) & 1u;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (ok ? xoff[u] : 0));   // invalid slots read the band origin (in bounds)
+      rx[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < WB_DS; ++u) {
+      const int p = (tid + u * CONV_NT) >> 4;
+      rd[u] = *reinterpret_cast<const f32x4*>(db + (size_t)(p < npx_d ? p : 0) * a.Cout);
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < XS; ++u) {
+      const int p = (tid + u * CONV_NT) >> 4;
+      if (p >= npx_x) break;
+      f32x4 xv = rx[u];
+      if (a.in_scale) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = fmaf(xv[j], sc4[j], sh4[j]);
+      }
+      if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xv[j] > 0.f ? xv[j] : xv[j] * slope;
+      }
+      if (!((rvalid >> u) & 1u)) xv = f32x4{0.f, 0.f, 0.f, 0.f};      // padding stays exactly zero
+      *reinterpret_cast<f32x4*>(&sX[p * WLD + c4]) = xv;
+    }
+#pragma unroll
+    for (int u = 0; u < WB_DS; ++u) {
+      const int p = (tid + u * CONV_NT) >> 4;
+      if (p < npx_d) *reinterpret_cast<f32x4*>(&sD[p * WLD + c4]) = rd[u];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // per-lane LDS bases (floats) and wave-uniform tap offsets
+  const int la = lh * WLD + wco + li, lb = lh * WLD + wci + li;
+  int tofs[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tofs[t] = ((t / 3) * PW + (t % 3)) * WLD;
+  const int halfw = W >> 1, npairs = R * halfw;
+
+  if (band_begin < band_end) stage_load(band_begin);
+  for (int band = band_begin; band < band_end; ++band) {
+    __syncthreads();                 // the MFMAs of the previous band are done reading LDS
+    stage_store();
+    __syncthreads();
+    if (band + 1 < band_end) stage_load(band + 1);
+    // ---- pixel pairs (r, 2*x2 + lh): A = dY, B_t = X shifted by tap t.  Fragments of pair i+1 are read while pair i's MFMAs run.
+    int pa = 0, pb = 0, x2 = 0;      // wave-uniform cursors (floats): dY pair base, X pair base (tap 0,0), pair column
+    auto advance = [&]() {
+      pa += 2 * WLD;
+      pb += 2 * WLD;
+      if (++x2 == halfw) { x2 = 0; pb += 2 * WLD; }
+    };
+    float av0 = sD[pa + la], av1;
+    float bv0[9], bv1[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) bv0[t] = sX[pb + tofs[t] + lb];
+    for (int i = 0; i < npairs; i += 2) {
+      advance();
+      av1 = sD[pa + la];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) bv1[t] = sX[pb + tofs[t] + lb];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[t], acc[t], 0, 0, 0);
+      if (i + 2 < npairs) advance();          // the prefetch after the last pair re-reads the last pair (stays in bounds)
+      av0 = sD[pa + la];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) bv0[t] = sX[pb + tofs[t] + lb];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[t], acc[t], 0, 0, 0);
+    }
+  }
+
+  // ---- one slab tile per tap: rows = co, cols = ci (lanes contiguous along ci)
+  const int ci = ci0 + wci + li;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* out = a.slab + ((size_t)chunk * 9 + t) * a.Cout * a.Cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      out[(size_t)co * a.Cin + ci] = acc[t][r];
+    }
+  }
+}
+
+// Plan of the band variant: rows per band R, bands per chunk, number of chunks - or R = 0 when the shape is not covered.
+struct WgBandPlan { int R, bpc, nchunk, nbands; size_t lds; };
+inline WgBandPlan wgrad_band_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
+  WgBandPlan best{0, 0, 0, 0, 0};
+  if (ksize != 3 || stride != 1 || (Cin & 63) || (Cout & 63) || (W & 3) || W < 4) return best;
+  if (const char* e = getenv("SST_WGRAD_BAND")) {
+    if (atoi(e) == 0) return best;
+  }
+  const int nblk = (Cout >> 6) * (Cin >> 6);
+  const long slots = 512;                  // 2 resident workgroups per CU
+  double best_cost = 1e30;
+  for (int R = 2; R >= 1; --R) {
+    if (H % R) continue;
+    const int npx_x = (R + 2) * (W + 2), npx_d = R * W;
+    if ((npx_x * 16 + CONV_NT - 1) / CONV_NT > WB_XS || (npx_d * 16 + CONV_NT - 1) / CONV_NT > WB_DS) continue;
+    const size_t lds = (size_t)(npx_x + npx_d) * WLD * sizeof(float);
+    if (lds > 78 * 1024) continue;
+    const long nbands = (long)B * (H / R);
+    const long per = (long)nblk * njobs;
+    long bpc = (nbands * per + slots - 1) / slots;
+    if (bpc < 1) bpc = 1;
+    const long nchunk = (nbands + bpc - 1) / bpc;
+    const long rounds = (nchunk * per + slots - 1) / slots;
+    // time ~ rounds * (bands of MFMA work per workgroup + fixed cost of the 9 slab tiles ~ 0.7 band of R = 2)
+    const double cost = (double)rounds * ((double)bpc * R + 1.4);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = WgBandPlan{R, (int)bpc, (int)nchunk, (int)nbands, lds};
+    }
+  }
+  return best;
+}
+
 // dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci]     (fixed chunk order: reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunk,
                                                            int KK, int Cout, int Cin, int accumulate, const WgJob* jobs) {
@@ -259,6 +448,40 @@ SST_API int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int 
   return (int)((M + chunk_px - 1) / chunk_px);
 }
 
+static long g_wgrad_band_launches = 0;
+SST_API long sst_debug_wgrad_band_launches(void) { return g_wgrad_band_launches; }   // test hook
+
+static int launch_wgrad_band(WgradArgs& a, const WgBandPlan& pl, int njobs, hipStream_t st) {
+  ++g_wgrad_band_launches;
+  static bool big_lds_enabled = false;
+  if (!big_lds_enabled) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_band_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            80 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_band_kernel<WB_XS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+      return sst_set_error(SST_ERR_HIP, "conv_wgrad_band: cannot raise the LDS limit");
+    big_lds_enabled = true;
+  }
+  a.R = pl.R; a.bpc = pl.bpc; a.nbands = pl.nbands; a.nchunk = pl.nchunk;
+  dim3 grid((unsigned)pl.nchunk * njobs, (a.Cout >> 6) * (a.Cin >> 6));
+  const int xslots = ((pl.R + 2) * (a.W + 2) * 16 + CONV_NT - 1) / CONV_NT;
+  if (xslots <= 7)
+    conv_wgrad_band_kernel<7><<<grid, CONV_NT, pl.lds, st>>>(a);
+  else
+    conv_wgrad_band_kernel<WB_XS><<<grid, CONV_NT, pl.lds, st>>>(a);
+  SST_LAUNCH_CHECK("conv_wgrad_band_kernel");
+  return SST_OK;
+}
+
+// Chunk count (slab floats per layer = chunks*k*k*Cout*Cin) that sst_conv_wgrad (njobs = 1) / sst_conv_wgrad_grouped use
+// for this shape; H, W are the INPUT size.
+SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
+  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
+  if (pl.R) return pl.nchunk;
+  const int pad = ksize / 2;
+  return sst_conv_wgrad_chunks(B, (H + 2 * pad - ksize) / stride + 1, (W + 2 * pad - ksize) / stride + 1, Cin, Cout, ksize);
+}
+
 SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
                            const float* in_shift, const float* in_slope, float in_slope_const, int in_act, int B, int H,
                            int W, int Cin, int Cout, int stride, int ksize, int accumulate, void* stream) {
@@ -274,7 +497,7 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
   const int64_t M = (int64_t)B * a.Ho * a.Wo;
   SST_REQUIRE(M < (1ll << 31), "sst_conv_wgrad: too many pixels");
-  const int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
+  int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
   a.chunk_px = (int)(((M + nchunk - 1) / nchunk + SUB - 1) / SUB * SUB);
   {
     const char* e = getenv("SST_WGRAD_DBG");
@@ -282,7 +505,12 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   }
   const int KK = ksize * ksize;
   dim3 grid(nchunk, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
-  if ((Cin & 3) == 0 && (Cout & 3) == 0)
+  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, 1);
+  if (pl.R) {
+    const int rc = launch_wgrad_band(a, pl, 1, sst_stream(stream));
+    if (rc != SST_OK) return rc;
+    nchunk = pl.nchunk;
+  } else if ((Cin & 3) == 0 && (Cout & 3) == 0)
     conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
   else
     conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
@@ -352,7 +580,12 @@ SST_API int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, in
   a.dbg = 0;
   const int KK = ksize * ksize;
   dim3 grid((unsigned)nchunk * njobs, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
-  if ((Cin & 3) == 0 && (Cout & 3) == 0)
+  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
+  if (pl.R) {
+    const int rc = launch_wgrad_band(a, pl, njobs, sst_stream(stream));
+    if (rc != SST_OK) return rc;
+    nchunk = pl.nchunk;
+  } else if ((Cin & 3) == 0 && (Cout & 3) == 0)
     conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
   else
     conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);

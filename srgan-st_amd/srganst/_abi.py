@@ -29,6 +29,7 @@ SIGNATURES = {
                                         P, c_int, P]),
     "sst_debug_big_tile_launches": (ctypes.c_long, []),
     "sst_debug_band_launches": (ctypes.c_long, []),
+    "sst_debug_wgrad_band_launches": (ctypes.c_long, []),
     "sst_conv_mtiles": (c_int, [c_int, c_int, c_int]),
     "sst_conv_stat_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_int,
@@ -37,6 +38,7 @@ SIGNATURES = {
     "sst_conv_dgrad_fused": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, P, P, c_float, c_int, P,
                                      c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_wgrad_chunks": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sst_conv_wgrad_chunks2": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_wgrad": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, P]),
     "sst_fill_table": (c_int, [P, POINTER(ctypes.c_longlong), c_int, P]),

@@ -104,7 +104,7 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
     cout = dy.shape[-1]
     ho, wo = conv_out_hw(H, W, ksize, stride)
     assert tuple(dy.shape) == (B, ho, wo, cout) and tuple(dw_out.shape) == (cout, cin, ksize, ksize)
-    nch = _abi.lib().sst_conv_wgrad_chunks(B, ho, wo, cin, cout, ksize)
+    nch = _abi.lib().sst_conv_wgrad_chunks2(B, H, W, cin, cout, ksize, stride, 1)
     slab = _f32(nch * ksize * ksize * cout * cin, like=x)
     e0 = _prof_begin()
     args = (ptr(x), ptr(dy), ptr(slab), ptr(dw_out), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const),
@@ -642,7 +642,7 @@ class WgradGroup:
                 conv_wgrad(x, dy, dw, k, s, in_scale=sc, in_shift=sh, in_slope=sl, in_slope_const=slc, in_act=act)
                 continue
             dev = js[0][0].device
-            nch = _abi.lib().sst_conv_wgrad_chunks(B, dys[1], dys[2], cin, cout, k)
+            nch = _abi.lib().sst_conv_wgrad_chunks2(B, H, W, cin, cout, k, s, len(js))
             per = nch * k * k * cout * cin
             key = (dev, xs, dys, k, s, len(js))
             ent = WgradGroup._cache.get(key)

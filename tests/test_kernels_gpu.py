@@ -372,3 +372,52 @@ def test_conv_band_kernel(ops, case, monkeypatch):
     assert rel_err(nchw(dy_b.cpu()), dyr) < TOL
     oref = torch.nn.grad.conv2d_input((B, Cout, H, W), wt.double(), dyr, 1, 1) + res.double()
     assert rel_err(nchw(out_b.cpu()), oref) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 48, 48, 64, 128), (3, 12, 12, 128, 64), (1, 9, 16, 64, 64), (2, 6, 8, 64, 64),
+                                  (16, 24, 24, 64, 64)])
+def test_conv_wgrad_band_kernel(ops, case, monkeypatch):
+    """The all-taps weight-gradient kernel (3x3, stride 1, channels multiples of 64) against fp64 autograd and against the
+    per-tap kernel (SST_WGRAD_BAND=0), single launch and grouped launch."""
+    from srganst import _abi
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(81)
+    n0 = _abi.lib().sst_debug_wgrad_band_launches()
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    xin = F.leaky_relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2)
+    y = F.conv2d(xin, w, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
+    kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), in_slope_const=0.2, in_act=ops.ACT_SLOPE)
+    dw = torch.full((Cout, Cin, 3, 3), 7.0).cuda()
+    ops.conv_wgrad(xd, dyd, dw, 3, 1, **kw)
+    assert _abi.lib().sst_debug_wgrad_band_launches() == n0 + 1
+    assert rel_err(dw.cpu(), w.grad) < TOL
+    ops.conv_wgrad(xd, dyd, dw, 3, 1, accumulate=True, **kw)
+    assert rel_err(dw.cpu(), 2 * w.grad) < TOL
+    monkeypatch.setenv("SST_WGRAD_BAND", "0")
+    dw_old = torch.empty_like(dw)
+    ops.conv_wgrad(xd, dyd, dw_old, 3, 1, **kw)
+    assert _abi.lib().sst_debug_wgrad_band_launches() == n0 + 2
+    monkeypatch.delenv("SST_WGRAD_BAND")
+    assert rel_err(dw_old.cpu(), w.grad) < TOL
+    # grouped: three layers of this shape (different data) in one launch
+    grp = ops.WgradGroup()
+    outs, refs = [], []
+    for i in range(3):
+        xi = torch.randn(B, Cin, H, W, generator=g)
+        wi = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        yi = F.conv2d(xi.double(), wi, None, 1, 1)
+        dyi = torch.randn(yi.shape, generator=g)
+        yi.backward(dyi.double())
+        o = torch.empty(Cout, Cin, 3, 3).cuda()
+        grp.add(nhwc(xi).cuda(), nhwc(dyi).cuda(), o, 3, 1)
+        outs.append(o)
+        refs.append(wi.grad)
+    grp.run()
+    assert _abi.lib().sst_debug_wgrad_band_launches() == n0 + 3
+    for o, r in zip(outs, refs):
+        assert rel_err(o.cpu(), r) < TOL
