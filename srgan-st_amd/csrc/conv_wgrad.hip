@@ -322,7 +322,8 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_wgrad_band_kernel(WgradArgs a
     __syncthreads();                 // the MFMAs of the previous band are done reading LDS
     stage_store();
     __syncthreads();
-    if (band + 1 < band_end) stage_load(band + 1);
+    if (band + 1 < band_end && !(a.dbg & 1)) stage_load(band + 1);
+    if (a.dbg & 2) continue;
     // ---- pixel pairs (r, 2*x2 + lh): A = dY, B_t = X shifted by tap t.  Fragments of pair i+1 are read while pair i's MFMAs run.
     int pa = 0, pb = 0, x2 = 0;      // wave-uniform cursors (floats): dY pair base, X pair base (tap 0,0), pair column
     auto advance = [&]() {
@@ -351,6 +352,10 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_wgrad_band_kernel(WgradArgs a
   }
 
   // ---- one slab tile per tap: rows = co, cols = ci (lanes contiguous along ci)
+  if (a.dbg & 4) {
+    if (acc[0][0] == 12345.f) a.slab[0] = 1.f;
+    return;
+  }
   const int ci = ci0 + wci + li;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -371,10 +376,16 @@ inline WgBandPlan wgrad_band_plan(int B, int H, int W, int Cin, int Cout, int ks
   if (const char* e = getenv("SST_WGRAD_BAND")) {
     if (atoi(e) == 0) return best;
   }
+  // small single layers stay with the per-tap kernel: a band workgroup's fixed cost (9 slab tiles) needs several bands of
+  // MFMA work behind it (measured: equal at 2.7 GFLOP, 1.3x faster at 10.9 GFLOP, 2.3x slower at 0.68 GFLOP)
+  if (2.0 * B * H * W * Cin * Cout * 9 * njobs < 2.5e9 && !getenv("SST_WGRAD_BAND")) return best;
   const int nblk = (Cout >> 6) * (Cin >> 6);
-  const long slots = 512;                  // 2 resident workgroups per CU
+  long slots = 512;                        // 2 resident workgroups per CU
+  int rmax = 2;
+  if (const char* e = getenv("SST_WGRAD_BAND_SLOTS")) slots = atoi(e);      // dev overrides
+  if (const char* e = getenv("SST_WGRAD_BAND_R")) rmax = atoi(e);
   double best_cost = 1e30;
-  for (int R = 2; R >= 1; --R) {
+  for (int R = rmax; R >= 1; --R) {
     if (H % R) continue;
     const int npx_x = (R + 2) * (W + 2), npx_d = R * W;
     if ((npx_x * 16 + CONV_NT - 1) / CONV_NT > WB_XS || (npx_d * 16 + CONV_NT - 1) / CONV_NT > WB_DS) continue;
@@ -404,6 +415,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw = jobs[blockIdx.y].dw;
   }
   const int64_t per_tap = (int64_t)Cout * Cin, total = per_tap * KK;
+  const bool split = accumulate & 2;      // flag bit 1: split variant
+  accumulate &= 1;
+  if (split) {
+    // split variant (many chunks): 64 float4 items per workgroup x 4 chunk groups; group cg sums chunks cg, cg+4, ...
+    // (fixed order), the 4 partial sums are combined in order through LDS - same result on every run
+    __shared__ f32x4 part[4][64];
+    const int item = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int64_t i4 = blockIdx.x * 64ll + item, total4 = total >> 2;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < total4) {
+#pragma unroll 4
+      for (int s = cg; s < nchunk; s += 4) t += *reinterpret_cast<const f32x4*>(slab + (size_t)s * total + (i4 << 2));
+    }
+    part[cg][item] = t;
+    __syncthreads();
+    if (cg == 0 && i4 < total4) {
+      t = part[0][item] + part[1][item];
+      t += part[2][item];
+      t += part[3][item];
+      const int64_t i = i4 << 2;
+      const int tap = (int)(i / per_tap);
+      const int64_t oc = i - (int64_t)tap * per_tap;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* d = dw + (oc + j) * KK + tap;
+        *d = accumulate ? *d + t[j] : t[j];
+      }
+    }
+    return;
+  }
   if ((Cin & 3) == 0) {
     const int64_t total4 = total >> 2;
     for (int64_t i4 = blockIdx.x * 256ll + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
@@ -446,6 +487,20 @@ SST_API int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int 
   if (want < 1) want = 1;
   int64_t chunk_px = ((M + want - 1) / want + SUB - 1) / SUB * SUB;
   return (int)((M + chunk_px - 1) / chunk_px);
+}
+
+// slab reduce launch: the split variant (flag bit 1 of `accumulate`) when there are many chunks to sum
+static void launch_wgrad_reduce(const float* slab, float* dw, int nchunk, int KK, int Cout, int Cin, int accumulate,
+                                const WgJob* jobs, int njobs, hipStream_t st) {
+  const int64_t total = (int64_t)KK * Cout * Cin;
+  if ((Cin & 3) == 0 && nchunk >= 8) {
+    const int blocks = (int)((total / 4 + 63) / 64);
+    wgrad_reduce_kernel<<<dim3(blocks, njobs), 256, 0, st>>>(slab, dw, nchunk, KK, Cout, Cin, (accumulate & 1) | 2, jobs);
+    return;
+  }
+  const int64_t items = (Cin & 3) == 0 ? total / 4 : total;
+  const int rb = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
+  wgrad_reduce_kernel<<<dim3(rb, njobs), 256, 0, st>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate, jobs);
 }
 
 static long g_wgrad_band_launches = 0;
@@ -515,10 +570,7 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   else
     conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
   SST_LAUNCH_CHECK("conv_wgrad_kernel");
-  const int64_t total = (int64_t)KK * Cout * Cin;
-  const int64_t items = (Cin & 3) == 0 ? total / 4 : total;
-  const int rb = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
-  wgrad_reduce_kernel<<<rb, 256, 0, sst_stream(stream)>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate, nullptr);
+  launch_wgrad_reduce(slab, dw, nchunk, KK, Cout, Cin, accumulate, nullptr, 1, sst_stream(stream));
   SST_LAUNCH_CHECK("wgrad_reduce_kernel");
   return SST_OK;
 }
@@ -590,10 +642,7 @@ SST_API int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, in
   else
     conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
   SST_LAUNCH_CHECK("conv_wgrad_kernel (grouped)");
-  const int64_t total = (int64_t)KK * Cout * Cin;
-  const int64_t items = (Cin & 3) == 0 ? total / 4 : total;
-  const int rb = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
-  wgrad_reduce_kernel<<<dim3(rb, njobs), 256, 0, sst_stream(stream)>>>(nullptr, nullptr, nchunk, KK, Cout, Cin, accumulate, a.jobs);
+  launch_wgrad_reduce(nullptr, nullptr, nchunk, KK, Cout, Cin, accumulate, a.jobs, njobs, sst_stream(stream));
   SST_LAUNCH_CHECK("wgrad_reduce_kernel (grouped)");
   return SST_OK;
 }

@@ -382,6 +382,7 @@ def test_conv_wgrad_band_kernel(ops, case, monkeypatch):
     from srganst import _abi
     B, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(81)
+    monkeypatch.setenv("SST_WGRAD_BAND", "1")          # force it also below the work threshold of the automatic choice
     n0 = _abi.lib().sst_debug_wgrad_band_launches()
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
@@ -402,7 +403,7 @@ def test_conv_wgrad_band_kernel(ops, case, monkeypatch):
     dw_old = torch.empty_like(dw)
     ops.conv_wgrad(xd, dyd, dw_old, 3, 1, **kw)
     assert _abi.lib().sst_debug_wgrad_band_launches() == n0 + 2
-    monkeypatch.delenv("SST_WGRAD_BAND")
+    monkeypatch.setenv("SST_WGRAD_BAND", "1")
     assert rel_err(dw_old.cpu(), w.grad) < TOL
     # grouped: three layers of this shape (different data) in one launch
     grp = ops.WgradGroup()

@@ -21,7 +21,10 @@ def timeit(fn, n=30, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (n * reps) * 1e3
 
-for (B, H, W, Cin, Cout, s) in [(16, 24, 24, 64, 64, 1), (16, 48, 48, 64, 256, 1), (16, 12, 12, 256, 512, 1), (16, 12, 12, 512, 512, 2)]:
+shapes = [(16, 24, 24, 64, 64, 1), (16, 24, 24, 64, 256, 1), (16, 48, 48, 64, 256, 1), (16, 12, 12, 256, 512, 1), (16, 12, 12, 512, 512, 2)]
+if len(sys.argv) > 1:
+    shapes = shapes[:int(sys.argv[1])]
+for (B, H, W, Cin, Cout, s) in shapes:
     x = torch.randn(B, H, W, Cin, device="cuda")
     ho, wo = ops.conv_out_hw(H, W, 3, s)
     dy = torch.randn(B, ho, wo, Cout, device="cuda")
