@@ -203,6 +203,12 @@ int sst_head_bwd(const float* h, const float* w, const float* dy, float* dh, flo
 int sst_flatten_act(const float* y, const float* scale, const float* shift, float slope, int act,
                     float* flat, int B, int HW, int C, void* stream);
 
+/* ---- optimizer: torch.optim.Adam(lr, betas, eps=1e-4) of train.py:62-75 / warmup.py:34-40 as ONE streaming pass over
+ * flat parameter / gradient / moment buffers (n floats, n % 4 == 0).  steps: nsteps device floats, all incremented by
+ * one (the per-parameter `step` tensors of torch's optimizer state); lr: device scalar (LR schedulers fill it). */
+int sst_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float* steps,
+                  int nsteps, double beta1, double beta2, double eps, double weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

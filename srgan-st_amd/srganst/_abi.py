@@ -28,6 +28,8 @@ SIGNATURES = {
     "sst_bwd_reduce_finalize": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P, c_float, P, P, P, P, P, P, P, P,
                                         P, c_int, P]),
     "sst_debug_big_tile_launches": (ctypes.c_long, []),
+    "sst_adam_flat": (c_int, [P, P, P, P, c_int64, P, P, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                            ctypes.c_double, P]),
     "sst_debug_band_launches": (ctypes.c_long, []),
     "sst_debug_wgrad_band_launches": (ctypes.c_long, []),
     "sst_conv_mtiles": (c_int, [c_int, c_int, c_int]),

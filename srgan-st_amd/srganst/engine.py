@@ -21,14 +21,11 @@ import torch
 from . import dist as sdist
 
 
-def make_adam(params, lr, betas, eps, weight_decay, capturable):
-    # torch.optim.Adam is third-party arithmetic the reference uses as-is (train.py:62-75); fused=True runs the
-    # same update in a handful of multi-tensor launches and is graph-capturable.
-    params = list(params)
-    if capturable:      # lr as a device tensor: LR schedulers fill_() it in place, so a captured graph sees the new value
-        lr = torch.tensor(float(lr), device=params[0].device, dtype=torch.float32)
-    return torch.optim.Adam(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True,
-                            capturable=capturable)
+def make_adam(module, lr, betas, eps, weight_decay, capturable):
+    # torch.optim.Adam semantics and state layout (the reference uses it as-is, train.py:62-75) on flat buffers: one
+    # HIP kernel per step, graph-capturable, lr as a device tensor so that LR schedulers keep working under capture.
+    from .optim import FlatAdam
+    return FlatAdam(module, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)
 
 
 class _GraphedStep:
@@ -83,7 +80,7 @@ class WarmupEngine:
         self.pg = process_group
         self.world = sdist.world_size(process_group)
         use_graph = config.KERNEL.USE_GRAPH if use_graph is None else use_graph
-        self.opt = make_adam(self.G.parameters(), config.SOLVER.G_BASE_LR, (config.SOLVER.G_BETA1, config.SOLVER.G_BETA2),
+        self.opt = make_adam(self.G, config.SOLVER.G_BASE_LR, (config.SOLVER.G_BETA1, config.SOLVER.G_BETA2),
                              config.SOLVER.G_EPS, config.SOLVER.G_WEIGHT_DECAY,
                              capturable=use_graph if adam_capturable is None else adam_capturable)
         self.gt = self.lr = None
@@ -146,8 +143,8 @@ class TrainEngine:
         use_graph = config.KERNEL.USE_GRAPH if use_graph is None else use_graph
         s = config.SOLVER
         cap = use_graph if adam_capturable is None else adam_capturable
-        self.g_opt = make_adam(self.G.parameters(), s.G_BASE_LR, (s.G_BETA1, s.G_BETA2), s.G_EPS, s.G_WEIGHT_DECAY, cap)
-        self.d_opt = make_adam(self.D.parameters(), s.D_BASE_LR, (s.D_BETA1, s.D_BETA2), s.D_EPS, s.D_WEIGHT_DECAY, cap)
+        self.g_opt = make_adam(self.G, s.G_BASE_LR, (s.G_BETA1, s.G_BETA2), s.G_EPS, s.G_WEIGHT_DECAY, cap)
+        self.d_opt = make_adam(self.D, s.D_BASE_LR, (s.D_BETA1, s.D_BETA2), s.D_EPS, s.D_WEIGHT_DECAY, cap)
         self.adv = BCEWithLogitsLoss()                      # train.py:59
         self.real = 1.0 - config.EXP.LABEL_SMOOTHING        # train.py:113
         self.fake = 0.0                                     # train.py:114

@@ -595,16 +595,22 @@ def conv_dgrad_fused(g, y2, wd, cout, ksize, cA=None, cB=None, cC=None, in_scale
     return out, dy, partial
 
 
-def flat_grads(module, names, params):
-    """One flat fp32 buffer + per-parameter views (reference order).  The buffer is remembered on the module so that
-    the data-parallel exchange can all-reduce it in place as ONE message (no flatten / unflatten copies)."""
-    # every view starts on a 64-byte boundary: the fused multi-tensor Adam falls off its vectorised path on
-    # misaligned gradients (measured 2x slower); the padding words are don.t-care (also in the all-reduce)
+def flat_layout(params):
+    """Offsets (in floats) of the per-parameter views inside a flat buffer, and its total size.  Every view starts on a
+    64-byte boundary (vector loads in the flat Adam kernel, aligned RCCL message); pad words are don't-care."""
     offs, off = [], 0
     for t in params:
         offs.append(off)
         off += (t.numel() + 15) // 16 * 16
-    flat = torch.empty(off, device=params[0].device, dtype=torch.float32)      # pad words are never read by anyone who cares
+    return offs, off
+
+
+def flat_grads(module, names, params):
+    """One flat fp32 buffer + per-parameter views (reference order).  The buffer is remembered on the module so that
+    the data-parallel exchange can all-reduce it in place as ONE message (no flatten / unflatten copies) and the flat
+    Adam (srganst.optim.FlatAdam) can consume it as one array."""
+    offs, total = flat_layout(params)
+    flat = torch.empty(total, device=params[0].device, dtype=torch.float32)      # pad words are never read by anyone who cares
     views = {n: flat[o:o + t.numel()].view(t.shape) for n, t, o in zip(names, params, offs)}
     # remember the last few buffers: with two backward passes per step (D on gt and on sr) autograd accumulates into the
     # FIRST pass's buffer, which is then the one holding p.grad
@@ -612,6 +618,31 @@ def flat_grads(module, names, params):
     lst.append(flat)
     del lst[:-4]
     return views
+
+
+def flatten_params(module):
+    """Move every parameter of `module` into ONE flat fp32 buffer (flat_layout order = named_parameters order, the same
+    layout flat_grads gives the gradients) and re-point the nn.Parameters at views of it.  Values, names, shapes and
+    state_dict are unchanged.  Returns (flat, offsets, params)."""
+    params = [p for _, p in module.named_parameters()]
+    ent = module.__dict__.get("_flat_params")
+    if ent is not None and all(p.data_ptr() == ent[0].data_ptr() + 4 * o for p, o in zip(params, ent[1])):
+        return ent[0], ent[1], params
+    offs, total = flat_layout(params)
+    flat = torch.zeros(total, device=params[0].device, dtype=torch.float32)
+    with torch.no_grad():
+        for p, o in zip(params, offs):
+            v = flat[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+    module.__dict__["_flat_params"] = (flat, offs)
+    return flat, offs, params
+
+
+def adam_flat(p, g, m, v, lr_dev, steps, beta1, beta2, eps, weight_decay):
+    assert p.numel() == g.numel() == m.numel() == v.numel() and p.numel() % 4 == 0
+    check(_abi.lib().sst_adam_flat(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(lr_dev), ptr(steps), steps.numel(),
+                                   float(beta1), float(beta2), float(eps), float(weight_decay), stream_ptr()), "sst_adam_flat")
 
 
 class WgradGroup:

@@ -81,7 +81,7 @@ def test_dp_world2_matches_mean_gradient_step(use_graph):
     cfg, G0 = _make(seed=3)                             # rank 0's init == the broadcast state
     _, G1 = _make(seed=3)
     G1.load_state_dict(G0.state_dict())
-    opt = make_adam(G0.parameters(), 1e-4, (0.9, 0.999), 1e-4, 0, capturable=True)
+    opt = make_adam(G0, 1e-4, (0.9, 0.999), 1e-4, 0, capturable=True)      # non-flat grads below: exercises the stock-Adam fallback
     mse, st = MSELoss(), StructureTensorLoss()
     for step in range(4):
         grads = []
