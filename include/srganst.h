@@ -155,6 +155,16 @@ int sst_bwd_apply_fused(const float* g, const float* g2, const float* y, const f
 int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean,
                      const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
                      float* cB, float* cC, float* dslope, int accumulate, void* stream);
+/* channel-parallel also with dslope (scratch: (C+63)/64 floats, counter: one zeroed word, left zero) */
+int sst_bwd_finalize_wide(const float* partial, int nblk, int C, float n, const float* mean, const float* rstd,
+                          const float* gamma, float* dgamma, float* dbeta, float* cA, float* cB, float* cC,
+                          float* dslope, int accumulate, float* scratch, unsigned* counter, void* stream);
+/* activation-only backward (PReLU / LeakyReLU, no BatchNorm) fused with the partial sums of the bias and slope
+ * gradients: dy = act'(y)*(g+g2), optionally stored pre-PixelShuffle; partial [sst_act_bwd_partial_blocks][3][C or 4C]
+ * in sst_bwd_finalize's layout (replaces reduce + finalize + apply + reduce + finalize of model.py:159-161's backward) */
+int sst_act_bwd_partial_blocks(int64_t stored_rows);
+int sst_act_bwd_partial(const float* g, const float* g2, const float* y, const float* slope, float slope_const,
+                        float* dy, float* partial, int64_t R, int C, int unshuffle_H, int unshuffle_W, void* stream);
 int sst_bwd_apply(const float* g, const float* g2, const float* y, const float* scale,
                   const float* shift, const float* slope, float slope_const, int act, const float* cA,
                   const float* cB, const float* cC, float* dy, int64_t R, int C, int unshuffle_H,

@@ -249,9 +249,11 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
 // when the scalar slope gradient is wanted, so that its sum over channels stays in one fixed-order reduction).
 // Thread (c = tid & 63, q = tid >> 6): 16 lanes per channel split the nblk partials (coalesced along c, 4-5 loads deep).
 constexpr int F2T = 1024;
-__global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f) {
+__global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f,
+                                                            float* __restrict__ scratch, unsigned* __restrict__ counter) {
   __shared__ float sm[3][F2T];
   __shared__ float red[F2T / 64];
+  __shared__ unsigned s_last;
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
   float al = 0.f;
   const int cstep = gridDim.x * 64;
@@ -301,10 +303,26 @@ __global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restr
       }
     }
   }
-  if (f.dslope) {                       // gridDim.x == 1 in this case (see the launcher)
+  if (f.dslope) {
     al = block_sum<F2T>(al, red);
-    if (threadIdx.x == 0) {
-      if (f.accumulate) f.dslope[0] += al; else f.dslope[0] = al;
+    if (gridDim.x == 1) {
+      if (threadIdx.x == 0) {
+        if (f.accumulate) f.dslope[0] += al; else f.dslope[0] = al;
+      }
+    } else {
+      // several workgroups (scratch / counter given): each publishes the sum over its channels, the last arriver adds them in
+      // workgroup order.  The hand-off is cheap HERE: this kernel has next to no dirty L2 lines for the release to write back.
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(scratch + blockIdx.x, al, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (publish_and_ticket(counter) == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) {
+          acquire_after_ticket();
+          float t = 0.f;
+          for (unsigned i = 0; i < gridDim.x; ++i) t += load_agent(scratch + i);
+          if (f.accumulate) f.dslope[0] += t; else f.dslope[0] = t;
+          __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
   }
 }
@@ -547,8 +565,21 @@ SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, con
   SST_REQUIRE(partial && nblk > 0 && C > 0, "sst_bwd_finalize: bad argument");
   SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize: BN mode needs all BN pointers");
   FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
-  bwd_finalize2_kernel<<<dslope ? 1 : (C + 63) / 64, F2T, 0, sst_stream(stream)>>>(partial, nblk, C, fin);
+  bwd_finalize2_kernel<<<dslope ? 1 : (C + 63) / 64, F2T, 0, sst_stream(stream)>>>(partial, nblk, C, fin, nullptr, nullptr);
   SST_LAUNCH_CHECK("bwd_finalize_kernel");
+  return SST_OK;
+}
+
+// Same, channel-parallel (one workgroup per 64 channels) also when the scalar slope gradient is wanted: scratch = (C+63)/64
+// floats, counter = one zeroed 32-bit word (left zero again).  For wide layers (the up-sampler's 256 channels).
+SST_API int sst_bwd_finalize_wide(const float* partial, int nblk, int C, float n, const float* mean, const float* rstd,
+                                  const float* gamma, float* dgamma, float* dbeta, float* cA, float* cB, float* cC,
+                                  float* dslope, int accumulate, float* scratch, unsigned* counter, void* stream) {
+  SST_REQUIRE(partial && nblk > 0 && C > 0 && scratch && counter, "sst_bwd_finalize_wide: bad argument");
+  SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize_wide: BN mode needs all BN pointers");
+  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
+  bwd_finalize2_kernel<<<(C + 63) / 64, F2T, 0, sst_stream(stream)>>>(partial, nblk, C, fin, scratch, counter);
+  SST_LAUNCH_CHECK("bwd_finalize_kernel (wide)");
   return SST_OK;
 }
 
@@ -562,6 +593,119 @@ SST_API int sst_bwd_apply(const float* g, const float* g2, const float* y, const
   bwd_apply_kernel<<<grid_for(R * (C / 4)), NT, 0, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, cA,
                                                                         cB, cC, dy, R, C, unshuffle_H, unshuffle_W);
   SST_LAUNCH_CHECK("bwd_apply_kernel");
+  return SST_OK;
+}
+
+// ---- activation-only backward with the partial sums of the bias / slope gradients in the same pass (no BatchNorm):
+//   gz = act'(y) * (g + g2),  dy = gz (optionally stored in the pre-PixelShuffle layout),
+//   partial[blk][0][c'] = sum gz,  partial[blk][1][c'] = 0,  partial[blk][2][c'] = sum (g+g2)*min(y,0)     over the block's rows
+// (c' = channel of the STORED tensor: 4c + 2(Y&1) + (X&1) when unshuffling) - the layout sst_bwd_finalize consumes, so the
+// bias gradient of the conv that produced y and the PReLU slope gradient come out of ONE finalize.  Replaces
+// [bwd_reduce, finalize, bwd_apply, bwd_reduce, finalize] of the up-sampling blocks (model.py:159-161 backward).
+// Unshuffle mode: a thread owns one OUTPUT pixel x one input channel quad: it reads the 4 sub-pixels (16 B each, coalesced
+// along channels) and writes 16 consecutive output channels (64 B).
+namespace {
+constexpr int AP_ROWS = 64;   // stored rows (pixels) per workgroup
+
+template <bool UNSH>
+__global__ __launch_bounds__(NT) void act_bwd_partial_kernel(const float* __restrict__ g, const float* __restrict__ g2,
+                                                             const float* __restrict__ y, const float* __restrict__ slope_p,
+                                                             float slope_c, float* __restrict__ dy, float* __restrict__ partial,
+                                                             int64_t Ro, int C, int oH, int oW) {
+  // Ro = stored rows; C = channels of g / y.  UNSH: stored tensor is [B,oH,oW,4C], g / y are [B,2oH,2oW,C].
+  constexpr int NV = UNSH ? 4 : 1;                 // f32x4 values per thread and row
+  __shared__ float sm[2][NT][NV * 4 + 1];
+  const int nq = C >> 2;                           // channel quads per input pixel (NT % nq == 0)
+  const int q = threadIdx.x % nq, pl = threadIdx.x / nq, npl = NT / nq;
+  const float slope = slope_p ? slope_p[0] : slope_c;
+  f32x4 s0[NV], s2[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s0[k] = s2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t r0 = (int64_t)blockIdx.x * AP_ROWS;
+  for (int rr = pl; rr < AP_ROWS; rr += npl) {
+    const int64_t r = r0 + rr;
+    if (r >= Ro) break;
+    if (UNSH) {
+      const int ox = (int)(r % oW);
+      const int64_t t = r / oW;
+      const int oy = (int)(t % oH);
+      const int64_t b = t / oH;
+      f32x4 o[4];
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {             // sub-pixel (i, j) = (sp >> 1, sp & 1)
+        const int64_t ip = ((b * 2 * oH + 2 * oy + (sp >> 1)) * 2 * oW + 2 * ox + (sp & 1)) * nq + q;
+        f32x4 gv = reinterpret_cast<const f32x4*>(g)[ip];
+        if (g2) gv += reinterpret_cast<const f32x4*>(g2)[ip];
+        const f32x4 yv = reinterpret_cast<const f32x4*>(y)[ip];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gz = yv[j] > 0.f ? gv[j] : gv[j] * slope;
+          // stored channel 4*(4q + j) + sp  ->  value j of the thread's sp-th ... regroup: output quad j holds sub-pixels 0..3
+          o[j][sp] = gz;
+          s0[j][sp] += gz;
+          s2[j][sp] = fmaf(gv[j], fminf(yv[j], 0.f), s2[j][sp]);
+        }
+      }
+      f32x4* d = reinterpret_cast<f32x4*>(dy) + r * (int64_t)(4 * nq) + 4 * q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = o[j];
+    } else {
+      const int64_t ip = r * nq + q;
+      f32x4 gv = reinterpret_cast<const f32x4*>(g)[ip];
+      if (g2) gv += reinterpret_cast<const f32x4*>(g2)[ip];
+      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[ip];
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gz = yv[j] > 0.f ? gv[j] : gv[j] * slope;
+        o[j] = gz;
+        s0[0][j] += gz;
+        s2[0][j] = fmaf(gv[j], fminf(yv[j], 0.f), s2[0][j]);
+      }
+      reinterpret_cast<f32x4*>(dy)[ip] = o;
+    }
+  }
+  // combine the npl row lanes (fixed order) and store the block's partial sums
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sm[0][threadIdx.x][k * 4 + j] = s0[k][j];
+      sm[1][threadIdx.x][k * 4 + j] = s2[k][j];
+    }
+  __syncthreads();
+  const int Cs = C * NV;                           // stored channels
+  for (int i = threadIdx.x; i < 2 * Cs; i += NT) {
+    const int which = i / Cs, c = i - which * Cs;  // stored channel c = (4*qq + k) * 4 + j  (UNSH)  or  4*qq + j
+    const int qq = c / (4 * NV), e = c - qq * 4 * NV;
+    float t = 0.f;
+    for (int l = 0; l < npl; ++l) t += sm[which][l * nq + qq][e];
+    partial[((size_t)blockIdx.x * 3 + (which ? 2 : 0)) * Cs + c] = t;
+  }
+  for (int c = threadIdx.x; c < Cs; c += NT) partial[((size_t)blockIdx.x * 3 + 1) * Cs + c] = 0.f;
+}
+}  // namespace
+
+SST_API int sst_act_bwd_partial_blocks(int64_t stored_rows) { return (int)((stored_rows + AP_ROWS - 1) / AP_ROWS); }
+
+// g, g2 (or null), y: [rows, C] of the activation's output/input; slope: device scalar or null (slope_const).
+// unshuffle_H/W = 0: dy [rows, C], partial [blocks][3][C].  Else g / y are [B, H, W, C] (H = unshuffle_H, ...) and dy is
+// [B, H/2, W/2, 4C] (inverse PixelShuffle(2)), partial [blocks][3][4C];  blocks = sst_act_bwd_partial_blocks(stored rows).
+SST_API int sst_act_bwd_partial(const float* g, const float* g2, const float* y, const float* slope, float slope_const, float* dy,
+                                float* partial, int64_t R, int C, int unshuffle_H, int unshuffle_W, void* stream) {
+  SST_REQUIRE(g && y && dy && partial && R > 0 && C >= 4 && (C & 3) == 0 && NT % (C >> 2) == 0,
+              "sst_act_bwd_partial: bad argument (C=%d must be a multiple of 4 with 256 %% (C/4) == 0)", C);
+  if (unshuffle_W) {
+    SST_REQUIRE((unshuffle_H & 1) == 0 && (unshuffle_W & 1) == 0 && R % ((int64_t)unshuffle_H * unshuffle_W) == 0,
+                "sst_act_bwd_partial: bad unshuffle geometry");
+    const int64_t Ro = R / 4;
+    act_bwd_partial_kernel<true><<<sst_act_bwd_partial_blocks(Ro), NT, 0, sst_stream(stream)>>>(
+        g, g2, y, slope, slope_const, dy, partial, Ro, C, unshuffle_H / 2, unshuffle_W / 2);
+  } else {
+    act_bwd_partial_kernel<false><<<sst_act_bwd_partial_blocks(R), NT, 0, sst_stream(stream)>>>(g, g2, y, slope, slope_const, dy,
+                                                                                                 partial, R, C, 0, 0);
+  }
+  SST_LAUNCH_CHECK("act_bwd_partial_kernel");
   return SST_OK;
 }
 

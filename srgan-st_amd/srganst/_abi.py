@@ -55,6 +55,9 @@ SIGNATURES = {
     "sst_bwd_apply_fused": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int, c_float, P, P, P, P, P, P, c_int, P, c_int64,
                                     c_int, c_int, c_int, P]),
     "sst_bwd_finalize": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P]),
+    "sst_bwd_finalize_wide": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P, P, P]),
+    "sst_act_bwd_partial_blocks": (c_int, [c_int64]),
+    "sst_act_bwd_partial": (c_int, [P, P, P, P, c_float, P, P, c_int64, c_int, c_int, c_int, P]),
     "sst_bwd_apply": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     "sst_add": (c_int, [P, P, P, c_int64, P]),
     "sst_slab_reduce": (c_int, [P, P, c_int, c_int64, c_int, P]),

@@ -151,9 +151,9 @@ def backward(module, params, sv, dsr, need_dx=False):
         pre = f"upsampling.{j}.upsample_block"
         u_in, slope_in, us = sv["ups"][j]
         sl = p[pre + ".2.weight"]
-        du = ops.bwd_reduce_apply(g, us, rows(us), slope=sl, act=1, dslope=grads[pre + ".2.weight"],
-                                  unshuffle=True)                                    # [B,h,w,4C] pre-shuffle grad
-        ops.bwd_finalize(ops.bwd_reduce(du, du), rows(du), dbeta=grads[pre + ".0.bias"])
+        # PReLU backward + inverse PixelShuffle + the partial sums of (conv bias, slope) gradients in ONE pass, one finalize
+        du = ops.act_bwd(g, us, slope=sl, dbias=grads[pre + ".0.bias"], dslope=grads[pre + ".2.weight"],
+                         unshuffle=True)                                             # [B,h,w,4C] pre-shuffle grad
         with ops.SideStream(u_in, du, grads[pre + ".0.weight"]):
             ops.conv_wgrad(u_in, du, grads[pre + ".0.weight"], 3, 1, in_slope=slope_in,
                            in_act=ACT_SLOPE if slope_in is not None else 0)
@@ -193,8 +193,7 @@ def backward(module, params, sv, dsr, need_dx=False):
         wg.add(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0)
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
-    dz1 = ops.bwd_reduce_apply(dh, z1, n, g2=dskip, slope=a1, act=1, dbeta=grads["conv1.0.bias"],
-                               dslope=grads["conv1.1.weight"])
+    dz1 = ops.act_bwd(dh, z1, g2=dskip, slope=a1, dbias=grads["conv1.0.bias"], dslope=grads["conv1.1.weight"])
     with ops.SideStream(dz1, sv["x3"], grads["conv1.0.weight"]):
         if fast9:
             ops.wgrad_c3(dz1, sv["x3"], grads["conv1.0.weight"], 1)

@@ -159,10 +159,37 @@ def bwd_finalize(partial, n, mean=None, rstd=None, gamma=None, dgamma=None, dbet
     cA = cB = cC = None
     if mean is not None:
         cA, cB, cC = (_f32(C, like=partial) for _ in range(3))
+    if dslope is not None and C > 64:        # wide layer: keep the finalize channel-parallel (last-arriver slope sum)
+        scratch = _f32((C + 63) // 64, like=partial)
+        check(_abi.lib().sst_bwd_finalize_wide(ptr(partial), nblk, C, float(n), ptr(mean), ptr(rstd), ptr(gamma), ptr(dgamma),
+                                               ptr(dbeta), ptr(cA), ptr(cB), ptr(cC), ptr(dslope), int(accumulate), ptr(scratch),
+                                               _next_counter(partial.device), stream_ptr()), "sst_bwd_finalize_wide")
+        return cA, cB, cC
     check(_abi.lib().sst_bwd_finalize(ptr(partial), nblk, C, float(n), ptr(mean), ptr(rstd), ptr(gamma), ptr(dgamma), ptr(dbeta),
                                       ptr(cA), ptr(cB), ptr(cC), ptr(dslope), int(accumulate), stream_ptr()),
           "sst_bwd_finalize")
     return cA, cB, cC
+
+
+def act_bwd(g, y, g2=None, slope=None, slope_const=0.0, dbias=None, dslope=None, accumulate=False, unshuffle=False):
+    """Backward through a slope activation without BatchNorm, one pass + one finalize: returns dy = act'(y) * (g + g2)
+    (in the pre-PixelShuffle layout [B,H/2,W/2,4C] when unshuffle), fills dbias (sum of dy per stored channel) and dslope."""
+    C = y.shape[-1]
+    R = y.numel() // C
+    uh = uw = 0
+    if unshuffle:
+        B, uh, uw, _ = y.shape
+        dy = _f32(B, uh // 2, uw // 2, 4 * C, like=y)
+    else:
+        dy = torch.empty_like(y)
+    Cs = dy.shape[-1]
+    nblk = _abi.lib().sst_act_bwd_partial_blocks(dy.numel() // Cs)
+    partial = _f32(nblk, 3, Cs, like=y)
+    check(_abi.lib().sst_act_bwd_partial(ptr(g), ptr(g2), ptr(y), ptr(slope), float(slope_const), ptr(dy), ptr(partial), R, C, uh, uw,
+                                         stream_ptr()), "sst_act_bwd_partial")
+    if dbias is not None or dslope is not None:
+        bwd_finalize(partial, R, dbeta=dbias, dslope=dslope, accumulate=accumulate)
+    return dy
 
 
 def bwd_apply(g, y, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, cA=None, cB=None, cC=None,

@@ -422,3 +422,25 @@ def test_conv_wgrad_band_kernel(ops, case, monkeypatch):
     assert _abi.lib().sst_debug_wgrad_band_launches() == n0 + 3
     for o, r in zip(outs, refs):
         assert rel_err(o.cpu(), r) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 16, 24, 64, True), (1, 6, 10, 16, True), (2, 13, 9, 64, False), (1, 48, 48, 64, True), (3, 5, 7, 8, False),
+                                  (1, 8, 8, 4, True)])
+def test_act_bwd_with_partials(ops, case):
+    """PReLU backward (+ inverse PixelShuffle) with bias / slope gradients from the same pass, against autograd in fp64."""
+    B, H, W, C, unsh = case
+    g = torch.Generator().manual_seed(91)
+    y = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)     # activation input (shuffled layout)
+    slope = torch.tensor([0.25], dtype=torch.float64, requires_grad=True)
+    up = torch.randn(B, C, H, W, generator=g)
+    up2 = torch.randn(B, C, H, W, generator=g)
+    F.prelu(y, slope).backward((up + up2).double())
+    dslope = torch.full((1,), 3.0).cuda()
+    Cs = 4 * C if unsh else C
+    dbias = torch.full((Cs,), 5.0).cuda()
+    dy = ops.act_bwd(nhwc(up).cuda(), nhwc(y.detach().float()).cuda(), g2=nhwc(up2).cuda(), slope=slope.detach().float().cuda(),
+                     dbias=dbias, dslope=dslope, unshuffle=unsh)
+    ref = F.pixel_unshuffle(y.grad, 2) if unsh else y.grad
+    assert rel_err(nchw(dy.cpu()), ref) < TOL
+    assert rel_err(dbias.cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
+    assert abs(float(dslope) - float(slope.grad)) < 1e-4 * max(1.0, abs(float(slope.grad)))
