@@ -165,15 +165,15 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--hr", type=int, default=96)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="keep weight gradients on the main stream (clean per-kernel profiles)")
+    ap.add_argument("--overlap", action="store_true", help="run the big single weight gradients on a side stream (off: measured slower)")
+    ap.add_argument("--no-overlap", action="store_true", help="(default) keep weight gradients on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
     from srganst import _abi, dist as sdist, ops as _ops
     _abi.lib()                                    # fail loudly if the HIP extension is missing
-    if args.no_overlap:
-        _ops.OVERLAP = False
+    _ops.OVERLAP = bool(args.overlap) and not args.no_overlap
     rank, local, world = sdist.init_from_env("nccl")
     if world != args.gpus:
         if rank == 0:

@@ -444,7 +444,7 @@ def flatten_bn_counters(module):
 # ------------------------------------------------------------------------------------------------
 # Second HIP stream for work that is off the critical chain of backward (weight gradients): under hipGraph
 # capture the fork/join below becomes two parallel branches of the graph.
-OVERLAP = True
+OVERLAP = False     # measured (round 1, MI355X): with the band kernels the side stream costs 7 % of the step - kept as an option
 _SIDE = {}
 
 
