@@ -28,6 +28,27 @@ def make_adam(module, lr, betas, eps, weight_decay, capturable):
     return FlatAdam(module, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)
 
 
+def _criterion_total(sr, gt, criterions, weights, adversarial=None):
+    """sum_name weight * criterion(sr, gt) as in the reference loops (train.py:129-140, warmup.py:79-86); the values come
+    back per name (already weighted, detached).  HIP-path pixel / structure-tensor terms share one autograd node
+    (loss.criterion_sum); "Adversarial" (through D) and any other criterion go through autograd term by term."""
+    from .loss import criterion_sum, fusable
+    vals = OrderedDict((name, None) for name in criterions)
+    fused = [n for n, c in criterions.items() if n != "Adversarial" and fusable(c)]
+    total = None
+    if fused:
+        total, weighted = criterion_sum(sr, gt, [criterions[n] for n in fused], [weights[n] for n in fused])
+        for i, n in enumerate(fused):
+            vals[n] = weighted[i]
+    for name, crit in criterions.items():
+        if name in fused:
+            continue
+        l = (adversarial(crit) if (name == "Adversarial" and adversarial is not None) else crit(sr, gt)) * weights[name]
+        vals[name] = l.detach()
+        total = l if total is None else total + l
+    return total, vals
+
+
 class _GraphedStep:
     """Capture ``fn()`` (which reads the static input buffers) into a hipGraph after a few eager warm-up calls."""
 
@@ -98,12 +119,7 @@ class WarmupEngine:
     def _fwd_bwd(self):
         self.opt.zero_grad(set_to_none=True)
         sr = self.G(self.lr)
-        total = None
-        vals = OrderedDict()
-        for name, crit in self.criterions.items():
-            l = crit(sr, self.gt) * self.weights[name]
-            vals[name] = l.detach()
-            total = l if total is None else total + l
+        total, vals = _criterion_total(sr, self.gt, self.criterions, self.weights)
         total.backward()
         self.sr = sr.detach()
         self.loss_values = vals
@@ -116,6 +132,12 @@ class WarmupEngine:
         vals = self._fwd_bwd()
         self.opt.step()
         return vals
+
+    def close(self):
+        """Drop the captured graphs and static buffers (also breaks the engine <-> bound-method reference cycle, so the
+        device objects are released right here and not by a later cyclic collection)."""
+        self._fb = self._op = None
+        self.gt = self.lr = self.sr = None
 
     def step(self, gt, lr):
         """One optimisation step on the batch (gt [B,3,H,W], lr [B,3,H/4,W/4], device tensors)."""
@@ -167,17 +189,8 @@ class TrainEngine:
             p.requires_grad = False
         self.g_opt.zero_grad(set_to_none=True)
         sr = self.G(self.lr)
-        total = None
-        vals = OrderedDict()
-        for name, crit in cfg.MODEL.G_LOSS.CRITERIONS.items():
-            w = cfg.MODEL.G_LOSS.CRITERION_WEIGHTS[name]
-            if name == "Adversarial":
-                l = crit(self.D(sr), self.real)
-            else:
-                l = crit(sr, self.gt)
-            l = l * w
-            vals[name] = l.detach()
-            total = l if total is None else total + l
+        total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
+                                       adversarial=lambda crit: crit(self.D(sr), self.real))
         total.backward()
         self.sr = sr.detach()
         self.loss_values = vals
@@ -206,6 +219,11 @@ class TrainEngine:
         v = self._d_fwd_bwd()
         self.d_opt.step()
         return v
+
+    def close(self):
+        """See WarmupEngine.close."""
+        self._g_fb = self._g_op = self._d_fb = self._d_op = None
+        self.gt = self.lr = self.sr = None
 
     def step(self, gt, lr):
         if self.gt is None:

@@ -110,6 +110,72 @@ class L1Loss(nn.Module):
         return _PixelLossFn.apply(x, gt, 1, self._ws)
 
 
+# ------------------------------------------------------------------------------------------------
+class _CriterionSumFn(torch.autograd.Function):
+    """total = sum_i w_i * criterion_i(sr, gt) for HIP-path criterions, as ONE autograd node: the weighted values and the
+    total come out of one tiny kernel, and the backward kernels of the terms accumulate into one d(sr) buffer with the
+    weight folded into their scale - no per-term mul / add launches (reference train.py:129-140 / warmup.py:79-86 loop)."""
+
+    @staticmethod
+    def forward(ctx, sr, gt, terms, weights, ws):
+        from . import ops
+        if sr.dtype != torch.float32 or sr.shape != gt.shape:
+            raise _abi.HipPathError("criterion sum: fp32 tensors of equal shape")
+        sr, gt = sr.contiguous(), gt.contiguous()
+        lib = _abi.lib()
+        raw, saved = [], []
+        for i, t in enumerate(terms):
+            if isinstance(t, StructureTensorLoss):
+                raw.append(_StLossFn.forward(_Ctx(saved), sr, gt, float(t.sigma), float(t.rho), bool(t.normalize), t._ws))
+            else:
+                raw.append(ops.pixel_loss_fwd(sr, gt, 0 if isinstance(t, MSELoss) else 1, t._ws))
+                saved.append(None)
+        n = len(terms)
+        total = torch.empty((), device=sr.device, dtype=torch.float32)
+        weighted = torch.empty(n, device=sr.device, dtype=torch.float32)
+        ptrs = (ctypes.c_void_p * n)(*[_abi.ptr(r) for r in raw])
+        wts = (ctypes.c_float * n)(*[float(w) for w in weights])
+        _abi.check(lib.sst_weighted_sum(ptrs, wts, n, _abi.ptr(total), _abi.ptr(weighted), _abi.stream_ptr()), "sst_weighted_sum")
+        ctx.terms, ctx.weights, ctx.gS = terms, [float(w) for w in weights], saved
+        ctx.save_for_backward(sr, gt)
+        ctx.mark_non_differentiable(weighted)
+        return total, weighted
+
+    @staticmethod
+    def backward(ctx, grad_total, _grad_weighted):
+        from . import ops
+        sr, gt = ctx.saved_tensors
+        g = grad_total.contiguous().to(torch.float32)
+        B, _, H, W = sr.shape
+        dsr = torch.empty_like(sr)
+        for i, (t, w) in enumerate(zip(ctx.terms, ctx.weights)):
+            if isinstance(t, StructureTensorLoss):
+                _abi.check(_abi.lib().sst_st_loss_bwd(_abi.ptr(sr), _abi.ptr(ctx.gS[i]), _abi.ptr(dsr), _abi.ptr(g), w, int(i > 0), B, H, W,
+                                                      float(t.sigma), float(t.rho), _abi.stream_ptr()), "sst_st_loss_bwd")
+            else:
+                ops.pixel_loss_bwd(sr, gt, 0 if isinstance(t, MSELoss) else 1, scale_dev=g, scale_host=w, out=dsr, accumulate=i > 0)
+        return dsr, None, None, None, None
+
+
+class _Ctx:
+    """Stand-in for an autograd ctx when a Function's forward is re-used inside another node: keeps the gS tensor."""
+
+    def __init__(self, saved):
+        self._saved = saved
+
+    def save_for_backward(self, x, gS):
+        self._saved.append(gS)
+
+
+def fusable(criterion) -> bool:
+    return isinstance(criterion, (MSELoss, L1Loss, StructureTensorLoss))
+
+
+def criterion_sum(sr, gt, terms, weights, ws=None):
+    """-> (total, weighted values [len(terms)]) for fusable() criterions of (sr, gt)."""
+    return _CriterionSumFn.apply(sr, gt, list(terms), list(weights), ws)
+
+
 class _BceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target_value):

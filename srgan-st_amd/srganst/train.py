@@ -14,7 +14,7 @@ from .config import Config
 from .dataset import TestImageDataset, TrainImageDataset
 from .engine import TrainEngine
 from .model import Discriminator, Generator
-from .utils import init_random_seed, load_state_dict
+from .utils import init_random_seed, load_state_dict, start_workers
 from .validate import _validate
 from .warmup import _NullWriter, _writer
 
@@ -29,6 +29,7 @@ def train(config: Config, train_dataset=None, test_dataset=None, max_steps_per_e
     train_loader = DataLoader(train_ds, batch_size=config.DATA.BATCH_SIZE, shuffle=sampler is None, sampler=sampler,
                               num_workers=1, pin_memory=True, drop_last=True, persistent_workers=True)
     test_loader = DataLoader(test_ds, batch_size=1, shuffle=False, num_workers=0, drop_last=False)
+    start_workers(train_loader)                  # fork the loader workers with the collector frozen (see utils.start_workers)
     discriminator = Discriminator(config).to(config.DEVICE)     # train.py:52-53: D is constructed before G
     generator = Generator(config).to(config.DEVICE)
     if config.MODEL.G_CONTINUE_FROM_WARMUP:
@@ -91,6 +92,7 @@ def train(config: Config, train_dataset=None, test_dataset=None, max_steps_per_e
                 torch.save(generator.state_dict(), results_dir + f"/g_epoch{epoch}.pth")
             if 0 < epoch and epoch % config.D_CHECKPOINT_INTERVAL == 0:
                 torch.save(discriminator.state_dict(), results_dir + f"/d_epoch{epoch}.pth")
+    engine.close()
     return generator, discriminator
 
 

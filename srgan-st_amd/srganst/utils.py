@@ -130,3 +130,23 @@ def bgr2ycbcr(img: np.ndarray, only_y: bool = True) -> np.ndarray:
     else:
         rlt /= 255.0
     return rlt.astype(in_img_type)
+
+
+def start_workers(loader):
+    """Fork a DataLoader's persistent workers NOW, with the garbage collector frozen across the fork.
+
+    The workers are forked from a process that owns HIP objects.  If unreachable-but-uncollected Python garbage that
+    holds device tensors or hipGraphs exists at fork time (e.g. the step engine of an earlier warmup() call, which sits in
+    a reference cycle), a cyclic collection INSIDE a worker would run those objects' destructors against a HIP runtime that
+    does not survive fork() - observed as "DataLoader worker killed by signal: Segmentation fault".  Collecting first and
+    freezing the survivors (the documented CPython recipe for fork) keeps the children's collector away from them."""
+    import gc
+    if getattr(loader, "num_workers", 0) == 0 or not getattr(loader, "persistent_workers", False):
+        return loader
+    gc.collect()
+    gc.freeze()
+    try:
+        iter(loader)          # creates the persistent iterator = forks the workers; later iter() calls re-use them
+    finally:
+        gc.unfreeze()
+    return loader

@@ -13,7 +13,7 @@ from .config import Config
 from .dataset import TestImageDataset, TrainImageDataset
 from .engine import WarmupEngine
 from .model import Generator
-from .utils import init_random_seed
+from .utils import init_random_seed, start_workers
 from .validate import _validate
 
 
@@ -43,6 +43,7 @@ def warmup(config: Config, train_dataset=None, test_dataset=None, max_steps_per_
     train_loader = DataLoader(train_ds, batch_size=config.DATA.BATCH_SIZE, shuffle=sampler is None, sampler=sampler,
                               num_workers=1, pin_memory=True, drop_last=True, persistent_workers=True)
     test_loader = DataLoader(test_ds, batch_size=1, shuffle=False, num_workers=0, drop_last=False)
+    start_workers(train_loader)                  # fork the loader workers with the collector frozen (see utils.start_workers)
     writer = _writer(config.EXP.NAME) if rank == 0 else _NullWriter()
     writer.add_text("Config/Params", config.get_all_params())
     batches_done = 0
@@ -81,6 +82,7 @@ def warmup(config: Config, train_dataset=None, test_dataset=None, max_steps_per_
                 best_psnr, best_ssim = psnr, ssim
             if 0 < epoch and epoch % config.G_CHECKPOINT_INTERVAL == 0:
                 torch.save(generator.state_dict(), results_dir + f"/g_epoch{epoch}.pth")
+    engine.close()
     return generator
 
 
