@@ -70,6 +70,11 @@ int sst_conv_dgrad_bwdstats(const float* x, const float* wp, float* y, const flo
                             const float* epi_scale, const float* epi_shift, const float* epi_slope,
                             float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
                             int Cout, int ksize, void* stream);
+/* forward conv on a not-yet-materialised residual sum h = x + y2*bn_scale + bn_shift (model.py:180-186 -> next block's conv):
+ * h is formed while the input tile is staged and also written to h_out; ones = [Cin] vector of 1.0f.  Replaces sst_bn_residual. */
+int sst_conv_fwd_resin(const float* x, const float* y2, const float* ones, const float* bn_scale, const float* bn_shift,
+                       float* h_out, const float* wp, float* y, const float* bias, float* stats, float* stats_cnt,
+                       int B, int H, int W, int Cin, int Cout, int ksize, void* stream);
 /* one launch per BatchNorm-backward stage: BN+activation backward apply on load (dy = cA*gz + cB*y2 + cC, also written
  * to dy_out for the weight-gradient kernel), data-gradient conv (+ residual), optional partials for the next stage. */
 int sst_conv_dgrad_fused(const float* g, const float* y2, const float* cA, const float* cB, const float* cC,

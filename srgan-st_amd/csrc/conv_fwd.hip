@@ -467,6 +467,19 @@ SST_API int sst_conv_dgrad_fused(const float* g, const float* y2, const float* c
                        epi_act, epi_partial, stream, y2, cA, cB, cC, dy_out);
 }
 
+// Forward conv whose input is a residual sum that has not been materialised yet (reference model.py:180-186:
+// out = x + rcb(x) feeding the next block's first conv):
+//   h = x + y2*bn_scale + bn_shift   (computed while the input tile is staged; also written to h_out for later consumers)
+//   y = conv(h, wp) (+ bias), optional BatchNorm partial statistics of y          - replaces one bn_residual launch.
+SST_API int sst_conv_fwd_resin(const float* x, const float* y2, const float* ones, const float* bn_scale, const float* bn_shift,
+                               float* h_out, const float* wp, float* y, const float* bias, float* stats, float* stats_cnt, int B,
+                               int H, int W, int Cin, int Cout, int ksize, void* stream) {
+  SST_REQUIRE(x && y2 && ones && bn_scale && bn_shift && h_out, "sst_conv_fwd_resin: null pointer");
+  return conv_fwd_impl(x, wp, y, nullptr, bias, nullptr, nullptr, nullptr, 0.f, ACT_NONE, nullptr, stats, stats_cnt, OUT_NHWC, B, H, W,
+                       Cin, Cout, ksize, 1, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, stream, y2, ones, bn_scale, bn_shift,
+                       h_out);
+}
+
 // ---- data-gradient of a 3x3 stride-2 pad-1 convolution (Discriminator.features, model.py:35,42,49,56)
 SST_API int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin) { return s2_class_offset(4, Cin, Cout); }
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "sst_conv_stat_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_fwd_resin": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_dgrad_bwdstats": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_dgrad_fused": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, P, P, c_float, c_int, P,
                                      c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -83,20 +83,30 @@ def forward(module, x, params, need_grad):
 
     h = z1
     blocks = []
+    pend = None       # (x, y2, scale2, shift2): the previous block's output h = x + BN2(y2), not materialised yet - the next
+                      # conv forms it while staging its input and hands it back (one bn_residual launch less per block)
     for i, blk in enumerate(module.trunk):
         pre = f"trunk.{i}.rcb"
         first = i == 0
-        y1, _, st, cnt = ops.conv_fwd(h, wp[pre + ".0.weight"], C, 3, 1,
-                                      in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0,
-                                      want_stats=training)
+        if pend is None:
+            y1, _, st, cnt = ops.conv_fwd(h, wp[pre + ".0.weight"], C, 3, 1,
+                                          in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0,
+                                          want_stats=training)
+        else:
+            y1, h, st, cnt = ops.conv_fwd_resin(*pend, wp[pre + ".0.weight"], C, 3, want_stats=training)
         m1, r1, s1, t1 = bn_affine(blk.rcb[1], pre + ".1", st, cnt)
         y2, _, st, cnt = ops.conv_fwd(y1, wp[pre + ".3.weight"], C, 3, 1, in_scale=s1, in_shift=t1,
                                       in_slope=p[pre + ".2.weight"], in_act=ACT_SLOPE, want_stats=training)
         m2, r2, s2, t2 = bn_affine(blk.rcb[4], pre + ".4", st, cnt)
-        h_next = ops.bn_residual(y2, s2, t2, h, a1 if first else None)
         blocks.append((h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2))
-        h = h_next
-    y3, _, st, cnt = ops.conv_fwd(h, wp["conv2.0.weight"], C, 3, 1, want_stats=training)
+        if first:     # the skip term is PReLU(z1) here: keep the stand-alone residual kernel
+            h, pend = ops.bn_residual(y2, s2, t2, h, a1), None
+        else:
+            pend = (h, y2, s2, t2)
+    if pend is None:
+        y3, _, st, cnt = ops.conv_fwd(h, wp["conv2.0.weight"], C, 3, 1, want_stats=training)
+    else:
+        y3, h, st, cnt = ops.conv_fwd_resin(*pend, wp["conv2.0.weight"], C, 3, want_stats=training)
     m3, r3, s3, t3 = bn_affine(module.conv2[1], "conv2.1", st, cnt)
     u = ops.bn_residual(y3, s3, t3, z1, a1)
     sv["blocks"], sv["h_last"], sv["conv2"] = blocks, h, (y3, m3, r3, s3, t3)

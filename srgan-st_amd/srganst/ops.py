@@ -97,6 +97,34 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
     return y, y_pre, stats, cnt
 
 
+_ONES = {}
+
+
+def conv_fwd_resin(x, y2, bn_scale, bn_shift, wp, cout, ksize=3, bias=None, want_stats=False):
+    """y = conv(h) with h = x + y2*bn_scale + bn_shift formed while staging (and returned): (y, h, stats|None, cnt|None)."""
+    B, H, W, cin = x.shape
+    key = (x.device, cin)
+    ones = _ONES.get(key)
+    if ones is None:
+        ones = _ONES[key] = torch.ones(cin, device=x.device, dtype=torch.float32)
+    y = _f32(B, H, W, cout, like=x)
+    h = torch.empty_like(x)
+    stats = cnt = None
+    if want_stats:
+        mt = _abi.lib().sst_conv_stat_tiles(B, H, W, cin, cout, ksize, 1)
+        stats = _f32(mt, 2, cout, like=x)
+        cnt = _f32(mt, like=x)
+    args = (ptr(x), ptr(y2), ptr(ones), ptr(bn_scale), ptr(bn_shift), ptr(h), ptr(wp), ptr(y), ptr(bias), ptr(stats), ptr(cnt),
+            B, H, W, cin, cout, ksize)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv_fwd_resin(*args, stream_ptr()), "sst_conv_fwd_resin")
+    flops = 2.0 * B * H * W * cout * cin * ksize * ksize
+    _prof_end(e0, f"conv_fwd_kernel<{ksize},1>", flops)
+    _trace(f"conv_fwd_kernel<{ksize},1>", flops, lambda: _abi.lib().sst_conv_fwd_resin(*args, stream_ptr()),
+           x, y2, ones, bn_scale, bn_shift, h, wp, y, bias, stats, cnt)
+    return y, h, stats, cnt
+
+
 def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,
                in_act=ACT_NONE, accumulate=False):
     """dw_out [Cout,Cin,k,k] (reference layout) (+)= wgrad.  x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC."""
