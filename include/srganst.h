@@ -55,6 +55,10 @@ int sst_conv_mtiles(int B, int Ho, int Wo);
 /* first dimension of stats / stats_cnt / epi_partial written by the NHWC-store conv of this shape (input H x W):
  * one tile per band when the band kernel takes the shape, else sst_conv_mtiles of the output size */
 int sst_conv_stat_tiles(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+/* kernel the conv / weight-gradient entries dispatch to for a shape (rocprofv3 spelling, no argument list): labels for
+ * bench.py's roofline rows, to be matched against profiles/ */
+const char* sst_conv_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int out_mode, int fused_in);
+const char* sst_conv_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs);
 long sst_debug_big_tile_launches(void);   /* test hook: launches of the 64x64-tile conv kernel so far */
 long sst_debug_band_launches(void);       /* test hook: launches of the band conv kernel so far */
 long sst_debug_wgrad_band_launches(void); /* test hook: launches of the all-taps weight-gradient kernel so far */

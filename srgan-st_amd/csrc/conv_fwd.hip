@@ -428,6 +428,24 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   return SST_OK;
 }
 
+// Name of the kernel sst_conv_fwd / sst_conv_dgrad_* dispatch to for this shape (as rocprofv3 prints it, without the
+// argument list) - bench.py labels its roofline rows with it so that they can be matched against profiles/.
+SST_API const char* sst_conv_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int out_mode, int fused_in) {
+  const int p = ksize / 2;
+  Conv3Args a{};
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.out_mode = out_mode;
+  a.Ho = (H + 2 * p - ksize) / stride + 1;
+  a.Wo = (W + 2 * p - ksize) / stride + 1;
+  a.in2 = fused_in ? reinterpret_cast<const float*>(1) : nullptr;
+  if (out_mode == OUT_NHWC) {
+    const int R = sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride);
+    if (R) return R * W / 16 == 9 ? "conv_band_kernel<9>" : "conv_band_kernel<3>";
+  }
+  if (use_big_tiles(a, ksize)) return stride == 1 ? "conv_fwd2_kernel<1>" : "conv_fwd2_kernel<2>";
+  if (ksize == 3) return stride == 1 ? "conv_fwd_kernel<3, 1>" : "conv_fwd_kernel<3, 2>";
+  return "conv_fwd_kernel<9, 1>";
+}
+
 SST_API int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias, const float* in_scale,
                          const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
                          const float* residual, float* stats, float* stats_cnt, int out_mode, int B, int H, int W, int Cin,

@@ -537,6 +537,13 @@ SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int k
   return sst_conv_wgrad_chunks(B, (H + 2 * pad - ksize) / stride + 1, (W + 2 * pad - ksize) / stride + 1, Cin, Cout, ksize);
 }
 
+// Name of the main kernel sst_conv_wgrad (njobs = 1) / sst_conv_wgrad_grouped launch for this shape (rocprofv3 spelling).
+SST_API const char* sst_conv_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
+  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
+  if (pl.R) return ((pl.R + 2) * (W + 2) * 16 + CONV_NT - 1) / CONV_NT <= 7 ? "conv_wgrad_band_kernel<7>" : "conv_wgrad_band_kernel<10>";
+  return ((Cin & 3) == 0 && (Cout & 3) == 0) ? "conv_wgrad_kernel<true>" : "conv_wgrad_kernel<false>";
+}
+
 SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
                            const float* in_shift, const float* in_slope, float in_slope_const, int in_act, int B, int H,
                            int W, int Cin, int Cout, int stride, int ksize, int accumulate, void* stream) {

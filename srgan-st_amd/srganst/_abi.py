@@ -27,6 +27,8 @@ SIGNATURES = {
     "sst_conv_pack_multi": (c_int, [P, c_int, c_int, P]),
     "sst_bwd_reduce_finalize": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P, c_float, P, P, P, P, P, P, P, P,
                                         P, c_int, P]),
+    "sst_conv_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sst_conv_wgrad_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_debug_big_tile_launches": (ctypes.c_long, []),
     "sst_adam_flat": (c_int, [P, P, P, P, c_int64, P, P, c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                             ctypes.c_double, P]),

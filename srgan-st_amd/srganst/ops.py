@@ -46,6 +46,14 @@ def _prof_end(e0, name, flops):
         PROFILE.append((name, flops, e0, e1))
 
 
+def _conv_name(B, H, W, cin, cout, ksize, stride, out_mode=0, fused_in=0):
+    return _abi.lib().sst_conv_kernel_name(B, H, W, cin, cout, ksize, stride, int(out_mode) & 0xff, int(fused_in)).decode()
+
+
+def _wgrad_name(B, H, W, cin, cout, ksize, stride, njobs):
+    return _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, cin, cout, ksize, stride, njobs).decode()
+
+
 def _f32(*shape, like):
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
@@ -91,8 +99,9 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
             int(in_act), ptr(residual), ptr(stats), ptr(cnt), int(out_mode), B, H, W, cin, cout, ksize, stride)
     check(_abi.lib().sst_conv_fwd(*args, stream_ptr()), "sst_conv_fwd")
     flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
-    _prof_end(e0, f"conv_fwd_kernel<{ksize},{stride}>", flops)
-    _trace(f"conv_fwd_kernel<{ksize},{stride}>", flops, lambda: _abi.lib().sst_conv_fwd(*args, stream_ptr()),
+    name = _conv_name(B, H, W, cin, cout, ksize, stride, out_mode) if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: _abi.lib().sst_conv_fwd(*args, stream_ptr()),
            x, wp, y, y_pre, bias, in_scale, in_shift, in_slope, residual, stats, cnt)
     return y, y_pre, stats, cnt
 
@@ -119,8 +128,9 @@ def conv_fwd_resin(x, y2, bn_scale, bn_shift, wp, cout, ksize=3, bias=None, want
     e0 = _prof_begin()
     check(_abi.lib().sst_conv_fwd_resin(*args, stream_ptr()), "sst_conv_fwd_resin")
     flops = 2.0 * B * H * W * cout * cin * ksize * ksize
-    _prof_end(e0, f"conv_fwd_kernel<{ksize},1>", flops)
-    _trace(f"conv_fwd_kernel<{ksize},1>", flops, lambda: _abi.lib().sst_conv_fwd_resin(*args, stream_ptr()),
+    name = _conv_name(B, H, W, cin, cout, ksize, 1, 0, 1) if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: _abi.lib().sst_conv_fwd_resin(*args, stream_ptr()),
            x, y2, ones, bn_scale, bn_shift, h, wp, y, bias, stats, cnt)
     return y, h, stats, cnt
 
@@ -139,8 +149,9 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
             int(in_act), B, H, W, cin, cout, stride, ksize, int(accumulate))
     check(_abi.lib().sst_conv_wgrad(*args, stream_ptr()), "sst_conv_wgrad")
     flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
-    _prof_end(e0, "conv_wgrad_kernel+reduce", flops)
-    _trace("conv_wgrad_kernel+wgrad_reduce_kernel", flops, lambda: _abi.lib().sst_conv_wgrad(*args, stream_ptr()),
+    name = (_wgrad_name(B, H, W, cin, cout, ksize, stride, 1) + "+wgrad_reduce_kernel") if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: _abi.lib().sst_conv_wgrad(*args, stream_ptr()),
            x, dy, slab, dw_out, in_scale, in_shift, in_slope)
     return dw_out
 
@@ -612,8 +623,9 @@ def conv_dgrad_bwdstats(dy, wd, cout, ksize, epi_y, residual=None, epi_scale=Non
     e0 = _prof_begin()
     check(_abi.lib().sst_conv_dgrad_bwdstats(*args, stream_ptr()), "sst_conv_dgrad_bwdstats")
     flops = 2.0 * B * H * W * cout * cin * ksize * ksize
-    _prof_end(e0, f"conv_fwd_kernel<{ksize},1>", flops)
-    _trace(f"conv_fwd_kernel<{ksize},1>", flops, lambda: _abi.lib().sst_conv_dgrad_bwdstats(*args, stream_ptr()),
+    name = _conv_name(B, H, W, cin, cout, ksize, 1) if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: _abi.lib().sst_conv_dgrad_bwdstats(*args, stream_ptr()),
            dy, wd, g, residual, epi_y, epi_scale, epi_shift, epi_slope, partial)
     return g, partial
 
@@ -644,8 +656,9 @@ def conv_dgrad_fused(g, y2, wd, cout, ksize, cA=None, cB=None, cC=None, in_scale
     e0 = _prof_begin()
     check(_abi.lib().sst_conv_dgrad_fused(*args, stream_ptr()), "sst_conv_dgrad_fused")
     flops = 2.0 * B * H * W * cout * cin * ksize * ksize
-    _prof_end(e0, f"conv_fwd_kernel<{ksize},1>", flops)
-    _trace(f"conv_fwd_kernel<{ksize},1>", flops, lambda: _abi.lib().sst_conv_dgrad_fused(*args, stream_ptr()),
+    name = _conv_name(B, H, W, cin, cout, ksize, 1, 0, 1) if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: _abi.lib().sst_conv_dgrad_fused(*args, stream_ptr()),
            g, y2, cA, cB, cC, in_scale, in_shift, in_slope, dy, wd, out, residual, epi_y, epi_scale, epi_shift, epi_slope, partial)
     return out, dy, partial
 
@@ -755,8 +768,9 @@ class WgradGroup:
             args = (ptr(ent["table"]), len(js), B, H, W, cin, cout, s, k, 0)
             check(_abi.lib().sst_conv_wgrad_grouped(*args, stream_ptr()), "sst_conv_wgrad_grouped")
             flops = 2.0 * B * dys[1] * dys[2] * cout * cin * k * k * len(js)
-            _prof_end(e0, "conv_wgrad_kernel(grouped)+reduce", flops)
+            name = (_wgrad_name(B, H, W, cin, cout, k, s, len(js)) + "(grouped)+wgrad_reduce_kernel") if (PROFILE is not None or TRACE is not None) else ""
+            _prof_end(e0, name, flops)
             table = ent["table"]
-            _trace("conv_wgrad_kernel(grouped)+wgrad_reduce_kernel", flops,
+            _trace(name, flops,
                    lambda args=args: _abi.lib().sst_conv_wgrad_grouped(*args, stream_ptr()), js, slab, table)
         self.jobs = []

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools_pmc_bench.sh) into profiles/pmc_traffic.json.
+
+usage: pmc_summarize.py <workload> <fetch_dir> <write_dir>
+HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: both counters are in KB; on gfx950
+FETCH_SIZE counts half of the wide coalesced reads, WRITE_SIZE is exact).  Keys are the kernel names as bench.py labels its
+roofline rows (rocprofv3 spelling without the argument list)."""
+import csv, glob, json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def base(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*$", "", name).strip()
+
+
+def collect(d, counter):
+    acc = {}
+    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")) + glob.glob(os.path.join(d, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            a = acc.setdefault(base(r["Kernel_Name"]), [0.0, 0])
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return acc
+
+
+def main():
+    workload, fd, wd = sys.argv[1:4]
+    fe, wr = collect(fd, "FETCH_SIZE"), collect(wd, "WRITE_SIZE")
+    out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    doc = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    raw, per = {}, {}
+    for k in sorted(set(fe) | set(wr)):
+        f, w = fe.get(k, [0.0, 0]), wr.get(k, [0.0, 0])
+        if not f[1] or not w[1]:
+            continue
+        raw[k] = {"FETCH_SIZE": {"avg_KB_per_launch": f[0] / f[1], "launches": f[1]},
+                  "WRITE_SIZE": {"avg_KB_per_launch": w[0] / w[1], "launches": w[1]}}
+        per[k] = (2.0 * f[0] / f[1] + w[0] / w[1]) * 1024.0
+    # bench.py's rows for the weight gradients time main kernel + slab reduce together: same for the traffic
+    for k in list(per):
+        if k.startswith("conv_wgrad") and "wgrad_reduce_kernel" in per:
+            per[k + "+wgrad_reduce_kernel"] = per[k] + per["wgrad_reduce_kernel"]
+            per[k + "(grouped)+wgrad_reduce_kernel"] = per[k] + per["wgrad_reduce_kernel"]
+    doc["_provenance"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over eager steps of "
+                          "bench.py (B=16), tools_pmc_bench.sh + tools/pmc_summarize.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                          "MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of wide coalesced reads; WRITE_SIZE exact); averages over "
+                          "all launches of a kernel name in the run")
+    doc.setdefault("_raw_KB", {})[workload] = raw
+    doc[workload] = per
+    json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
+    for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12]:
+        print(f"{k:60s} {v/1e6:9.2f} MB/launch")
+
+
+if __name__ == "__main__":
+    main()
