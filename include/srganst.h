@@ -202,6 +202,10 @@ int sst_pixel_loss_bwd(const float* x, const float* gt, float* dx, const float* 
                        float scale_host, int accumulate, int64_t n, int mode, void* stream);
 int sst_bce_logits(const float* logits, float target, float* loss, float* dlogits,
                    const float* scale_dev, float scale_host, int n, void* stream);
+/* MATLAB-style antialiased bicubic resampling of bicubic.py:15-105 (LR synthesis of dataset.py:28) with host-built tap
+ * tables: x [planes,H,W] -> y [planes,oh,ow]; wy/iy [oh,Ty], wx/ix [ow,Tx]; round_grid: round to the 1/255 grid (no clamp) */
+int sst_bicubic(const float* x, float* y, const float* wy, const int* iy, const float* wx, const int* ix,
+                int64_t planes, int H, int W, int oh, int ow, int Ty, int Tx, int round_grid, void* stream);
 int sst_weighted_sum(const float* const* terms, const float* weights, int n, float* out, float* weighted,
                      void* stream);
 

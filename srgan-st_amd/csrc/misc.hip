@@ -287,6 +287,46 @@ SST_API int sst_bce_logits(const float* logits, float target, float* loss, float
   return SST_OK;
 }
 
+// ---- MATLAB-style antialiased bicubic resampling (reference bicubic.py:15-105, used by dataset.py:28 to synthesise the LR
+// input).  Separable gather-multiply-sum with host-built tap tables (weights normalised, border indices clamped):
+//   V[oy][x] = sum_ty wy[oy][ty] * in[iy[oy][ty]][x];   out[oy][ox] = round(255 * sum_tx wx[ox][tx] * V[oy][ix[ox][tx]]) / 255
+// (vertical pass first, taps in table order - the reference's order; rounding to the 1/255 grid, no clamp).
+// One thread per output pixel; the input plane (36.9 KB at 96x96) is L1/L2-resident, the op is launch/HBM-bound.
+namespace {
+__global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ wy,
+                                                      const int* __restrict__ iy, const float* __restrict__ wx,
+                                                      const int* __restrict__ ix, int64_t planes, int H, int W, int oh, int ow, int Ty,
+                                                      int Tx, int round_grid) {
+  const int64_t total = planes * oh * ow;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % ow);
+    const int64_t t = i / ow;
+    const int oy = (int)(t % oh);
+    const float* src = x + (t / oh) * (int64_t)H * W;
+    float acc = 0.f;
+    for (int tx = 0; tx < Tx; ++tx) {
+      const int cx = ix[ox * Tx + tx];
+      float v = 0.f;
+      for (int ty = 0; ty < Ty; ++ty) v += src[(int64_t)iy[oy * Ty + ty] * W + cx] * wy[oy * Ty + ty];
+      acc += v * wx[ox * Tx + tx];
+    }
+    y[i] = round_grid ? rintf(255.f * acc) / 255.f : acc;
+  }
+}
+}  // namespace
+
+// x [planes, H, W] -> y [planes, oh, ow]; wy/iy [oh, Ty], wx/ix [ow, Tx] (fp32 weights, int32 0-based indices, device memory).
+SST_API int sst_bicubic(const float* x, float* y, const float* wy, const int* iy, const float* wx, const int* ix, int64_t planes,
+                        int H, int W, int oh, int ow, int Ty, int Tx, int round_grid, void* stream) {
+  SST_REQUIRE(x && y && wy && iy && wx && ix && planes > 0 && H > 0 && W > 0 && oh > 0 && ow > 0 && Ty > 0 && Tx > 0,
+              "sst_bicubic: bad argument");
+  const int64_t total = planes * oh * ow;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  bicubic_kernel<<<blocks, 256, 0, sst_stream(stream)>>>(x, y, wy, iy, wx, ix, planes, H, W, oh, ow, Ty, Tx, round_grid);
+  SST_LAUNCH_CHECK("bicubic_kernel");
+  return SST_OK;
+}
+
 SST_API int sst_weighted_sum(const float* const* terms, const float* weights, int n, float* out, float* weighted,
                              void* stream) {
   SST_REQUIRE(terms && weights && out && n > 0 && n <= 8, "sst_weighted_sum: 1..8 terms");

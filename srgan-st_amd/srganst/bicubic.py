@@ -1,8 +1,9 @@
 """MATLAB-imresize-compatible antialiased bicubic resampling.  Mirrors reference bicubic.py:15-105
 (used by dataset.py:28 to synthesise the LR input: x1/4, 16 taps per axis, weights normalised, border
 indices clamped, result rounded to the 1/255 grid and NOT clamped).  Same gather-multiply-sum order
-as the reference so results are bit-identical on the CPU; works on device tensors too (the index /
-weight tables are built on the host once per shape and cached)."""
+as the reference so results are bit-identical on the CPU.  On a ROCm tensor the resampling is ONE HIP kernel
+(csrc/misc.hip: sst_bicubic, SURVEY 8f-2: LR synthesis on device) driven by the same host-built tap tables; the CPU
+branch is the data-loader's host code (dataset.py runs in a worker process, like the reference's), not a fallback."""
 from __future__ import annotations
 
 import math
@@ -60,6 +61,17 @@ class Bicubic(nn.Module):
             w1, i1 = _contribute(w, ow, scale)
             self._cache[key] = tuple(t.to(input.device) for t in (w0, i0, w1, i1))
         w0, i0, w1, i1 = self._cache[key]
+        if input.is_cuda:
+            from . import _abi
+            k2 = key + ("i32",)
+            if k2 not in self._cache:
+                self._cache[k2] = (i0.to(torch.int32).contiguous(), i1.to(torch.int32).contiguous())
+            j0, j1 = self._cache[k2]
+            x = input.contiguous().to(torch.float32)
+            out = torch.empty(b, c, oh, ow, device=input.device, dtype=torch.float32)
+            _abi.check(_abi.lib().sst_bicubic(_abi.ptr(x), _abi.ptr(out), _abi.ptr(w0), _abi.ptr(j0), _abi.ptr(w1), _abi.ptr(j1), b * c,
+                                              h, w, oh, ow, w0.shape[1], w1.shape[1], 1, _abi.stream_ptr()), "sst_bicubic")
+            return out
         out = input[:, :, i0, :] * w0.unsqueeze(0).unsqueeze(1).unsqueeze(4)        # [b,c,oh,taps,w]
         out = torch.sum(out, dim=3)
         A = out.permute(0, 1, 3, 2)                                                 # [b,c,w,oh]

@@ -102,6 +102,8 @@ class Config:
         self.KERNEL = dotdict()
         self.KERNEL.USE_GRAPH = True        # capture the train step into a hipGraph
         self.KERNEL.SYNC_LOSS_EVERY_STEP = False  # reference does .item() per criterion per step (train.py:141)
+        self.KERNEL.LR_ON_DEVICE = False    # True: the LR batch is synthesised from the GT batch on the GPU (sst_bicubic, same
+                                            # values as dataset.py:28 on the 1/255 grid) instead of taking the loader's copy
 
     def add_g_criterion(self, name: str, value, weight: float = 1.0) -> None:
         self.MODEL.G_LOSS.CRITERIONS[name] = value

@@ -10,6 +10,7 @@ from torch.optim import lr_scheduler
 from torch.utils.data import DataLoader
 
 from . import dist as sdist
+from .bicubic import Bicubic
 from .config import Config
 from .dataset import TestImageDataset, TrainImageDataset
 from .engine import TrainEngine
@@ -29,6 +30,7 @@ def train(config: Config, train_dataset=None, test_dataset=None, max_steps_per_e
     train_loader = DataLoader(train_ds, batch_size=config.DATA.BATCH_SIZE, shuffle=sampler is None, sampler=sampler,
                               num_workers=1, pin_memory=True, drop_last=True, persistent_workers=True)
     test_loader = DataLoader(test_ds, batch_size=1, shuffle=False, num_workers=0, drop_last=False)
+    device_bicubic = Bicubic(config.DEVICE)
     start_workers(train_loader)                  # fork the loader workers with the collector frozen (see utils.start_workers)
     discriminator = Discriminator(config).to(config.DEVICE)     # train.py:52-53: D is constructed before G
     generator = Generator(config).to(config.DEVICE)
@@ -56,7 +58,10 @@ def train(config: Config, train_dataset=None, test_dataset=None, max_steps_per_e
             if max_steps_per_epoch is not None and batch_num >= max_steps_per_epoch:
                 break
             gt = gt.to(device=config.DEVICE, non_blocking=True)
-            lr = lr.to(device=config.DEVICE, non_blocking=True)
+            if config.KERNEL.LR_ON_DEVICE:
+                lr = device_bicubic(gt, scale=1.0 / config.DATA.UPSCALE_FACTOR)
+            else:
+                lr = lr.to(device=config.DEVICE, non_blocking=True)
             loss_values, d_now = engine.step(gt, lr)
             d_loss = d_now if d_now is not None else d_loss
             if batch_num % config.LOG_TRAIN_PERIOD != 0 or rank != 0:

@@ -9,6 +9,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dist as sdist
+from .bicubic import Bicubic
 from .config import Config
 from .dataset import TestImageDataset, TrainImageDataset
 from .engine import WarmupEngine
@@ -43,6 +44,7 @@ def warmup(config: Config, train_dataset=None, test_dataset=None, max_steps_per_
     train_loader = DataLoader(train_ds, batch_size=config.DATA.BATCH_SIZE, shuffle=sampler is None, sampler=sampler,
                               num_workers=1, pin_memory=True, drop_last=True, persistent_workers=True)
     test_loader = DataLoader(test_ds, batch_size=1, shuffle=False, num_workers=0, drop_last=False)
+    device_bicubic = Bicubic(config.DEVICE)
     start_workers(train_loader)                  # fork the loader workers with the collector frozen (see utils.start_workers)
     writer = _writer(config.EXP.NAME) if rank == 0 else _NullWriter()
     writer.add_text("Config/Params", config.get_all_params())
@@ -58,7 +60,10 @@ def warmup(config: Config, train_dataset=None, test_dataset=None, max_steps_per_
                 break
             batches_done += 1
             gt = gt.to(device=config.DEVICE, non_blocking=True)
-            lr = lr.to(device=config.DEVICE, non_blocking=True)
+            if config.KERNEL.LR_ON_DEVICE:
+                lr = device_bicubic(gt, scale=1.0 / config.DATA.UPSCALE_FACTOR)
+            else:
+                lr = lr.to(device=config.DEVICE, non_blocking=True)
             loss_values = engine.step(gt, lr)
             if batch_num % config.LOG_TRAIN_PERIOD != 0 or rank != 0:
                 continue

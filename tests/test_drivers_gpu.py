@@ -68,6 +68,7 @@ def test_warmup_and_train_drivers(tmp_path, monkeypatch):
     cfg2.add_g_criterion("Pixel", MSELoss(), 1.0)
     cfg2.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
     cfg2.SOLVER.D_UPDATE_INTERVAL = 2
+    cfg2.KERNEL.LR_ON_DEVICE = True          # LR batches synthesised on the GPU from the GT batches (sst_bicubic)
     G3, D3 = train(cfg2, train_dataset=train_ds, test_dataset=_Pairs(), max_steps_per_epoch=5)
     for f in ("g_last.pth", "d_last.pth"):
         assert os.path.exists(os.path.join("results/gan", f))
@@ -78,3 +79,23 @@ def test_warmup_and_train_drivers(tmp_path, monkeypatch):
     psnr, ssim = run_test(cfg2, save_images=False, g_path="results/gan/g_last.pth", dataset=_Pairs())
     assert 5.0 < psnr < 60.0 and -1.0 <= ssim <= 1.0
     assert os.path.exists(os.path.join(cfg2.DATA.TEST_SR_IMAGES_DIR, "gan", "_metrics.txt"))
+
+
+def test_bicubic_on_device_matches_reference_golden_and_host_path():
+    """sst_bicubic (LR synthesis on the GPU) against the reference's own outputs (tests/golden/bicubic.npz) and
+    against the host path the data loader uses - equal on the 1/255 grid."""
+    import numpy as np
+    from srganst.bicubic import Bicubic
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bicubic.npz"))
+    hr = torch.from_numpy(g["hr_u8"]).float() / 255
+    out = Bicubic("cuda")(hr.cuda(), scale=0.25)
+    assert out.shape == (1, 3, 24, 24) and torch.equal(out.cpu(), torch.from_numpy(g["lr"]))
+    step = torch.zeros(1, 3, 96, 96)
+    step[..., 48:] = 1.0
+    s = Bicubic("cuda")(step.cuda(), scale=0.25).cpu()
+    assert torch.equal(s, torch.from_numpy(g["step_lr"])) and float(s.min()) < 0 and float(s.max()) > 1
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (5, 3, 192, 96), generator=gen).float() / 255          # non-square, batch > 1
+    a, b = Bicubic("cpu")(x, scale=0.25), Bicubic("cuda")(x.cuda(), scale=0.25).cpu()
+    # identical except where 255*x lands within float rounding of a half-way point (summation order differs)
+    assert float((a - b).abs().max()) <= 1.0 / 255 + 1e-7 and float((a != b).float().mean()) < 1e-3
