@@ -368,6 +368,80 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_wgrad_band_kernel(WgradArgs a
   }
 }
 
+// ---- 3x3 / stride 1 weight gradient of a layer with a 3-CHANNEL input (Discriminator.features[0], model.py:32): MFMA tiles
+// would be 3/64 occupied (the general kernel runs this shape at 2 TFLOP/s), so this one is plain VALU: a workgroup owns a
+// band of R image rows, the 3-channel input patch sits in LDS, thread (co = tid % 64, pixel lane = tid / 64) keeps the 27
+// accumulators dW[co][ci][ky][kx] and walks its pixels: one coalesced dY load + 27 FMAs on LDS broadcasts per pixel.
+// Partials go to the usual slab [chunk = band][tap][Cout][3]; wgrad_reduce_kernel sums them.
+constexpr int C3_ROWS = 8;
+__global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ slab, int B, int H, int W, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];        // [(R+2)][(W+2)*3 + 3]  zero-padded patch
+  __shared__ float red[3][64][28];
+  const int bands = (H + C3_ROWS - 1) / C3_ROWS;
+  const int b = blockIdx.x / bands, y0 = (blockIdx.x - b * bands) * C3_ROWS;
+  const int rows = min(C3_ROWS, H - y0);
+  const int RS = (W + 2) * 3 + 3;
+  for (int i = threadIdx.x; i < (C3_ROWS + 2) * RS; i += CONV_NT) {
+    const int r = i / RS, o = i - r * RS;
+    const int px = o / 3 - 1, y = y0 - 1 + r;
+    float v = 0.f;
+    if (o < (W + 2) * 3 && (unsigned)px < (unsigned)W && (unsigned)y < (unsigned)H)
+      v = x[(((size_t)b * H + y) * W + px) * 3 + (o - (px + 1) * 3)];
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int co = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  for (int cob = blockIdx.y * 64; cob < Cout; cob += gridDim.y * 64) {
+    float acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+    if (cob + co < Cout) {
+      // pixels p = pl + 4*i of the band; 8 dY loads in flight per thread (a one-load-per-iteration loop is pure latency)
+      constexpr int UNR = 8;
+      const int npx = rows * W;
+      const float* dyb = dy + ((size_t)b * H + y0) * W * Cout + cob + co;
+      for (int p0 = pl; p0 < npx; p0 += UNR * (CONV_NT / 64)) {
+        float g[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int p = p0 + u * (CONV_NT / 64);
+          g[u] = p < npx ? dyb[(size_t)p * Cout] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int p = min(p0 + u * (CONV_NT / 64), npx - 1);      // clamped: g is 0 for the overshoot
+          const int r = p / W, c = p - r * W;
+          const float* w0 = xs + r * RS + c * 3;          // window top-left = patch (r, c): 3 rows x 9 contiguous floats
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) acc[ky * 9 + q] = fmaf(g[u], w0[ky * RS + q], acc[ky * 9 + q]);     // q = kx*3 + ci
+        }
+      }
+    }
+    // combine the 4 pixel lanes in fixed order, then store [tap][co][ci]
+    __syncthreads();
+    if (pl > 0) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) red[pl - 1][co][k] = acc[k];
+    }
+    __syncthreads();
+    if (pl == 0 && cob + co < Cout) {
+      float* out = slab + (size_t)blockIdx.x * 9 * Cout * 3;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const float t = ((acc[k] + red[0][co][k]) + red[1][co][k]) + red[2][co][k];
+        const int ky = k / 9, kx = (k % 9) / 3, ci = k % 3;
+        out[((size_t)(ky * 3 + kx) * Cout + cob + co) * 3 + ci] = t;
+      }
+    }
+  }
+}
+inline bool k3c3_applies(int Cin, int ksize, int stride, const float* in_scale, int in_act) {
+  return Cin == 3 && ksize == 3 && stride == 1 && !in_scale && in_act == ACT_NONE;
+}
+
 // Plan of the band variant: rows per band R, bands per chunk, number of chunks - or R = 0 when the shape is not covered.
 struct WgBandPlan { int R, bpc, nchunk, nbands; size_t lds; };
 inline WgBandPlan wgrad_band_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
@@ -465,6 +539,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       const int tap = (int)(i / per_tap);
       const int64_t oc = i - (int64_t)tap * per_tap;
       float t = 0.f;
+#pragma unroll 8
       for (int s = 0; s < nchunk; ++s) t += slab[(size_t)s * total + i];
       float* d = dw + oc * KK + tap;
       *d = accumulate ? *d + t : t;
@@ -534,6 +609,10 @@ SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int k
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
   if (pl.R) return pl.nchunk;
   const int pad = ksize / 2;
+  if (Cin == 3 && ksize == 3 && stride == 1) {         // 3-channel-input kernel (one chunk per band) or the general one
+    const int a = B * ((H + C3_ROWS - 1) / C3_ROWS), g = sst_conv_wgrad_chunks(B, H, W, Cin, Cout, ksize);
+    return a > g ? a : g;
+  }
   return sst_conv_wgrad_chunks(B, (H + 2 * pad - ksize) / stride + 1, (W + 2 * pad - ksize) / stride + 1, Cin, Cout, ksize);
 }
 
@@ -541,6 +620,7 @@ SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int k
 SST_API const char* sst_conv_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
   if (pl.R) return ((pl.R + 2) * (W + 2) * 16 + CONV_NT - 1) / CONV_NT <= 7 ? "conv_wgrad_band_kernel<7>" : "conv_wgrad_band_kernel<10>";
+  if (Cin == 3 && ksize == 3 && stride == 1) return "wgrad_k3c3_kernel";
   return ((Cin & 3) == 0 && (Cout & 3) == 0) ? "conv_wgrad_kernel<true>" : "conv_wgrad_kernel<false>";
 }
 
@@ -572,6 +652,11 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
     const int rc = launch_wgrad_band(a, pl, 1, sst_stream(stream));
     if (rc != SST_OK) return rc;
     nchunk = pl.nchunk;
+  } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && !getenv("SST_WGRAD_NO_K3C3")) {
+    nchunk = B * ((H + C3_ROWS - 1) / C3_ROWS);
+    const size_t lds = (size_t)(C3_ROWS + 2) * ((W + 2) * 3 + 3) * sizeof(float);
+    SST_REQUIRE(lds <= 48 * 1024, "sst_conv_wgrad: image too wide for the 3-channel-input kernel (W=%d)", W);
+    wgrad_k3c3_kernel<<<dim3(nchunk, 1), CONV_NT, lds, sst_stream(stream)>>>(x, dy, slab, B, H, W, Cout);
   } else if ((Cin & 3) == 0 && (Cout & 3) == 0)
     conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
   else

@@ -444,3 +444,27 @@ def test_act_bwd_with_partials(ops, case):
     assert rel_err(nchw(dy.cpu()), ref) < TOL
     assert rel_err(dbias.cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
     assert abs(float(dslope) - float(slope.grad)) < 1e-4 * max(1.0, abs(float(slope.grad)))
+
+
+@pytest.mark.parametrize("case", [(2, 24, 20, 64), (1, 96, 96, 64), (3, 13, 9, 128), (2, 8, 8, 16)])
+def test_conv_wgrad_three_channel_input(ops, case, monkeypatch):
+    """Weight gradient of a 3x3 stride-1 conv with a 3-channel input (Discriminator.features[0]): dedicated VALU kernel vs
+    fp64 autograd and vs the general kernel."""
+    B, H, W, Cout = case
+    g = torch.Generator().manual_seed(95)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(Cout, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), w, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    from srganst import _abi
+    assert _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, 3, Cout, 3, 1, 1) == b"wgrad_k3c3_kernel"
+    dw = torch.full((Cout, 3, 3, 3), 7.0).cuda()
+    ops.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw, 3, 1)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+    ops.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw, 3, 1, accumulate=True)
+    assert rel_err(dw.cpu(), 2 * w.grad) < TOL
+    monkeypatch.setenv("SST_WGRAD_NO_K3C3", "1")
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw2, 3, 1)
+    assert rel_err(dw2.cpu(), w.grad) < TOL
