@@ -68,7 +68,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_band_kernel(Conv3Args a, int R, 
     // patch pixel p = it*16 + lane/4  ->  (py, px), advanced incrementally (no per-iteration division)
     int p = lane >> 2;
     int py = p / PW, px = p - py * PW;
-    constexpr int UN = 4;
+    constexpr int UN = 7;      // 24x24: the 104-pixel patch is ONE batch of loads (two batches = two exposed latencies)
     const int nit = (a.dbg & 1) ? 0 : (npatch + 15) / 16;
     for (int it0 = 0; it0 < nit; it0 += UN) {
       f32x4 v[UN], yv[UN];
