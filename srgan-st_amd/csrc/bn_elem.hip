@@ -24,23 +24,56 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict
                                                          float* __restrict__ run_var, float* __restrict__ mean_out,
                                                          float* __restrict__ rstd_out, float* __restrict__ scale,
                                                          float* __restrict__ shift, float eps, float momentum) {
-  __shared__ float red[NT / 64];
+  __shared__ float red[2][NT / 64];
   const int c = blockIdx.x;
+  // One global round trip: a thread keeps its (up to KT) tiles' (sum, M2, count) in registers for both passes of Chan's
+  // combination, and the two first-pass sums share one pair of barriers (this kernel is pure latency: ~1 us of work
+  // behind a ~2.5 us launch, 33 times per step).
+  constexpr int KT = 4;
+  float ts[KT], tm[KT], tn[KT];
   float s = 0.f, n = 0.f;
-  for (int t = threadIdx.x; t < ntiles; t += NT) {
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const int t = threadIdx.x + k * NT;
+    ts[k] = tm[k] = tn[k] = 0.f;
+    if (t < ntiles) {
+      ts[k] = stats[(size_t)t * 2 * C + c];
+      tm[k] = stats[(size_t)t * 2 * C + C + c];
+      tn[k] = cnt[t];
+    }
+    s += ts[k];
+    n += tn[k];
+  }
+  for (int t = threadIdx.x + KT * NT; t < ntiles; t += NT) {      // more than KT*NT tiles: plain loop for the rest
     s += stats[(size_t)t * 2 * C + c];
     n += cnt[t];
   }
-  s = block_sum<NT>(s, red);
-  n = block_sum<NT>(n, red);
+  {
+    s = wave_sum(s);
+    n = wave_sum(n);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wid] = s; red[1][wid] = n; }
+    __syncthreads();
+    s = n = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) { s += red[0][i]; n += red[1][i]; }
+    __syncthreads();
+  }
   const float mean = s / n;
   float m2 = 0.f;
-  for (int t = threadIdx.x; t < ntiles; t += NT) {
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    if (tn[k] > 0.f) {
+      const float d = ts[k] / tn[k] - mean;
+      m2 += tm[k] + tn[k] * d * d;                                  // Chan et al. parallel variance
+    }
+  }
+  for (int t = threadIdx.x + KT * NT; t < ntiles; t += NT) {
     const float nt = cnt[t];
     const float d = stats[(size_t)t * 2 * C + c] / nt - mean;
-    m2 += stats[(size_t)t * 2 * C + C + c] + nt * d * d;   // Chan et al. parallel variance
+    m2 += stats[(size_t)t * 2 * C + C + c] + nt * d * d;
   }
-  m2 = block_sum<NT>(m2, red);
+  m2 = block_sum<NT>(m2, red[0]);
   if (threadIdx.x == 0) {
     const float var = m2 / n;
     const float rstd = 1.f / sqrtf(var + eps);
@@ -261,7 +294,7 @@ __global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restr
     const int c = cb + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if (c < C) {
-#pragma unroll 4
+#pragma unroll 12
       for (int b = q; b < nblk; b += F2T / 64) {
         const float* p = partial + (size_t)b * 3 * C + c;
         s0 += p[0];
