@@ -74,6 +74,20 @@ int sst_conv_dgrad_bwdstats(const float* x, const float* wp, float* y, const flo
                             const float* epi_scale, const float* epi_shift, const float* epi_slope,
                             float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
                             int Cout, int ksize, void* stream);
+/* ---- accumulator mode of the BatchNorm statistics (trunk shape only: sst_conv_acc_supported): the producer conv adds its
+ * per-band (sum, Chan-form sum of squares) into fp64 accumulators acc[nrep][C][2] (zero before the launch) with hardware
+ * atomics; the consumer conv derives batch statistics + affine of its input from them in its prologue and publishes
+ * mean / rstd / scale / shift (+ running statistics) once.  Replaces sst_bn_finalize launches of model.py:174-177's BatchNorms.
+ * in2 == null: staged = act(x*scale+shift); in2 != null: staged = x + in2*scale + shift, also written to side_out. */
+int sst_conv_acc_supported(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int sst_conv_fwd_acc(const float* x, const float* in2, float* side_out, const float* ones, const float* wp, float* y,
+                     const float* bias, const float* in_slope, float in_slope_const, int in_act, const double* in_acc,
+                     const float* in_gamma, const float* in_beta, float in_n, float eps, float momentum, float* o_mean,
+                     float* o_rstd, float* o_scale, float* o_shift, float* run_mean, float* run_var, double* st_acc,
+                     int nrep, int B, int H, int W, int Cin, int Cout, int ksize, void* stream);
+int sst_bn_finalize_acc(const double* acc, int nrep, int C, float n, const float* gamma, const float* beta,
+                        float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
+                        float eps, float momentum, void* stream);
 /* forward conv on a not-yet-materialised residual sum h = x + y2*bn_scale + bn_shift (model.py:180-186 -> next block's conv):
  * h is formed while the input tile is staged and also written to h_out; ones = [Cin] vector of 1.0f.  Replaces sst_bn_residual. */
 int sst_conv_fwd_resin(const float* x, const float* y2, const float* ones, const float* bn_scale, const float* bn_shift,

@@ -89,6 +89,34 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict
   }
 }
 
+// Forward finalize from fp64 accumulators acc[nrep][C][2] = (sum, sum of squares in Chan form), the layout the band conv
+// kernel adds into in accumulator mode (conv_epilogue.h: BandAcc) - for BatchNorm layers whose consumer is not a band conv.
+__global__ void bn_finalize_acc_kernel(const double* __restrict__ acc, int nrep, int C, float nf, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale,
+                                       float* __restrict__ shift, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double A = 0.0, Bq = 0.0;
+  for (int r = 0; r < nrep; ++r) {
+    A += acc[((size_t)r * C + c) * 2];
+    Bq += acc[((size_t)r * C + c) * 2 + 1];
+  }
+  const double n = (double)nf, mean = A / n;
+  double m2 = Bq - A * mean;
+  if (m2 < 0.0) m2 = 0.0;
+  const float rstd = 1.f / sqrtf((float)(m2 / n) + eps);
+  const float sc = gamma[c] * rstd;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(m2 / fmax(n - 1.0, 1.0));
+  }
+}
+
 // eval mode: scale/shift from the running statistics
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ run_mean, const float* __restrict__ run_var,
@@ -491,6 +519,16 @@ SST_API int sst_bn_finalize(const float* stats, const float* cnt, int ntiles, in
   bn_finalize_kernel<<<C, NT, 0, sst_stream(stream)>>>(stats, cnt, ntiles, C, gamma, beta, run_mean, run_var, mean, rstd,
                                                         scale, shift, eps, momentum);
   SST_LAUNCH_CHECK("bn_finalize_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_bn_finalize_acc(const double* acc, int nrep, int C, float n, const float* gamma, const float* beta, float* run_mean,
+                                float* run_var, float* mean, float* rstd, float* scale, float* shift, float eps, float momentum,
+                                void* stream) {
+  SST_REQUIRE(acc && nrep > 0 && C > 0 && n > 0.f && gamma && beta && mean && rstd && scale && shift, "sst_bn_finalize_acc: bad argument");
+  bn_finalize_acc_kernel<<<(C + 63) / 64, 64, 0, sst_stream(stream)>>>(acc, nrep, C, n, gamma, beta, run_mean, run_var, mean, rstd, scale,
+                                                                       shift, eps, momentum);
+  SST_LAUNCH_CHECK("bn_finalize_acc_kernel");
   return SST_OK;
 }
 

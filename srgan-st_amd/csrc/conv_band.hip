@@ -20,17 +20,23 @@
 #include "conv_epilogue.h"
 #include <cstdlib>
 
-int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st);
+int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st, const BandAcc* acc);
 int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+
+namespace {
+
+}  // namespace
+
 
 namespace {
 
 constexpr int PSTR = 20;   // LDS floats per patch pixel of one wave's 16-channel slice (16 + 4 pad: conflict-free b128 reads)
 
 template <int NB>
-__global__ __launch_bounds__(CONV_NT) void conv_band_kernel(Conv3Args a, int R, int nbands) {
+__global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(Conv3Args a, int R, int nbands, BandAcc ba) {   // NB = 3: keep 3 workgroups per CU (<= 168 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sstat[4][3][16];
+  __shared__ float saff[4][2][16];
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int W = a.W, PW = W + 2, npatch = (R + 2) * PW;
@@ -62,6 +68,62 @@ __global__ __launch_bounds__(CONV_NT) void conv_band_kernel(Conv3Args a, int R, 
       kB = *reinterpret_cast<const f32x4*>(a.in_cB + c);
       kC = *reinterpret_cast<const f32x4*>(a.in_cC + c);
     }
+    bool have_aff = a.in_scale != nullptr, have_k = a.in_cA != nullptr;
+    // BatchNorm affine of the input from the producer's accumulators (accumulator mode), before the patch loads (keeping the
+    // 32 accumulator registers alive across the patch loads was measured: spills, every variant slower).
+    // All 64 lanes load: lane = (channel j = lane % 16, part = lane / 16) takes replicas part, part + 4, ... (independent
+    // 16-B loads); the 4 parts are combined in fixed order with shuffles; lane j < 16 of wave w then owns channel 16w + j.
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    constexpr int MAXR = 8;                                 // replicas per lane (nrep <= 32)
+    f64x2 accv[MAXR];
+    if (ba.in_acc) {
+      const int ch = wave * 16 + (lane & 15), part = lane >> 4;
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) {
+        const int r = part + 4 * k;
+        accv[k] = f64x2{0.0, 0.0};
+        if (r < ba.nrep) accv[k] = *reinterpret_cast<const f64x2*>(ba.in_acc + ((size_t)r * 64 + ch) * 2);
+      }
+    }
+    auto affine_from_acc = [&]() {
+      double A = 0.0, Bq = 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) { A += accv[k][0]; Bq += accv[k][1]; }
+      A += __shfl_xor(A, 16, 64);
+      Bq += __shfl_xor(Bq, 16, 64);
+      A += __shfl_xor(A, 32, 64);
+      Bq += __shfl_xor(Bq, 32, 64);
+      if (lane < 16) {
+        const int ch = wave * 16 + lane;
+        const double n = (double)ba.in_n;
+        const double mean = A / n;
+        double m2 = Bq - A * mean;                         // = sum (x - mean)^2
+        if (m2 < 0.0) m2 = 0.0;
+        const float var = (float)(m2 / n);
+        const float rstd = 1.f / sqrtf(var + ba.in_eps);
+        const float scv = ba.in_gamma[ch] * rstd;
+        const float shv = ba.in_beta[ch] - (float)mean * scv;
+        saff[wave][0][lane] = scv;
+        saff[wave][1][lane] = shv;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {          // one workgroup publishes the statistics for the backward pass
+          if (ba.o_mean) { ba.o_mean[ch] = (float)mean; ba.o_rstd[ch] = rstd; ba.o_scale[ch] = scv; ba.o_shift[ch] = shv; }
+          if (ba.run_mean) {
+            ba.run_mean[ch] = (1.f - ba.momentum) * ba.run_mean[ch] + ba.momentum * (float)mean;
+            ba.run_var[ch] = (1.f - ba.momentum) * ba.run_var[ch] + ba.momentum * (float)(m2 / fmax(n - 1.0, 1.0));
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private exchange through LDS
+      f32x4 s4, t4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s4[j] = saff[wave][0][q4 + j];
+        t4[j] = saff[wave][1][q4 + j];
+      }
+      if (ba.in_target == 0) { sc = s4; sh = t4; have_aff = true; }
+      else { kB = s4; kC = t4; have_k = true; }
+    };
+    if (ba.in_acc) affine_from_acc();
     const float* xb = a.x + (size_t)b * a.H * W * 64 + c;
     const float* x2b = a.in2 ? a.in2 + (size_t)b * a.H * W * 64 + c : nullptr;
     float* sob = (a.side_out && g == 0) ? a.side_out + (size_t)b * a.H * W * 64 + c : nullptr;
@@ -105,11 +167,11 @@ __global__ __launch_bounds__(CONV_NT) void conv_band_kernel(Conv3Args a, int R, 
                 const float z = fmaf(yv[u][j], sc[j], sh[j]);
                 gz = z > 0.f ? gz : gz * slope;
               }
-              t[j] = a.in_cA ? fmaf(kA[j], gz, fmaf(kB[j], yv[u][j], kC[j])) : gz;
+              t[j] = have_k ? fmaf(kA[j], gz, fmaf(kB[j], yv[u][j], kC[j])) : gz;
             }
             if (sob && own[u]) *reinterpret_cast<f32x4*>(sob + off[u]) = t;
           } else {
-            if (a.in_scale) {
+            if (have_aff) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) t[j] = fmaf(t[j], sc[j], sh[j]);
             }
@@ -211,7 +273,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_band_kernel(Conv3Args a, int R, 
     return t;
   };
 
-  if (a.stats) {
+  if (a.stats || ba.st_acc) {
     // per-band (sum, centred M2) per output channel
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -241,10 +303,19 @@ __global__ __launch_bounds__(CONV_NT) void conv_band_kernel(Conv3Args a, int R, 
     }
     __syncthreads();
     if (tid < 16) {
-      float* st = a.stats + (size_t)mt * 2 * a.Cout + g * 16 + tid;
-      st[0] = sstat[0][0][tid] + sstat[1][0][tid] + sstat[2][0][tid] + sstat[3][0][tid];
-      st[a.Cout] = sstat[0][1][tid] + sstat[1][1][tid] + sstat[2][1][tid] + sstat[3][1][tid];
-      if (tid == 0 && g == 0) a.stats_cnt[mt] = (float)npx;
+      const float tot = sstat[0][0][tid] + sstat[1][0][tid] + sstat[2][0][tid] + sstat[3][0][tid];
+      const float m2t = sstat[0][1][tid] + sstat[1][1][tid] + sstat[2][1][tid] + sstat[3][1][tid];
+      if (a.stats) {
+        float* st = a.stats + (size_t)mt * 2 * a.Cout + g * 16 + tid;
+        st[0] = tot;
+        st[a.Cout] = m2t;
+        if (tid == 0 && g == 0) a.stats_cnt[mt] = (float)npx;
+      }
+      if (ba.st_acc) {      // A += sum, Bq += M2 + n_b * mean_b^2   (fp64 hardware atomics, no return value needed)
+        double* p = ba.st_acc + ((size_t)(b % ba.nrep) * a.Cout + g * 16 + tid) * 2;
+        __builtin_amdgcn_global_atomic_fadd_f64(p, (double)tot);
+        __builtin_amdgcn_global_atomic_fadd_f64(p + 1, (double)m2t + (double)tot * (double)tot / (double)npx);
+      }
     }
   }
 
@@ -328,8 +399,10 @@ int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int st
 static long g_band_launches = 0;
 SST_API long sst_debug_band_launches(void) { return g_band_launches; }   // test hook: how often the band kernel was chosen
 
-int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st) {
+int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st, const BandAcc* acc) {
   ++g_band_launches;
+  BandAcc ba{};
+  if (acc) ba = *acc;
   const int NB = R * a.W / 16, nbands = a.H / R;
   dim3 grid((unsigned)(a.B * nbands), a.Cout / 16);
   const size_t lds = band_lds_bytes(R, a.W, NB);
@@ -343,9 +416,9 @@ int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st) {
     big_lds_enabled = true;
   }
   if (NB == 9)
-    conv_band_kernel<9><<<grid, CONV_NT, lds, st>>>(a, R, nbands);
+    conv_band_kernel<9><<<grid, CONV_NT, lds, st>>>(a, R, nbands, ba);
   else if (NB == 3)
-    conv_band_kernel<3><<<grid, CONV_NT, lds, st>>>(a, R, nbands);
+    conv_band_kernel<3><<<grid, CONV_NT, lds, st>>>(a, R, nbands, ba);
   else
     return sst_set_error(SST_ERR_UNSUPPORTED, "conv_band: NB=%d not built", NB);
   SST_LAUNCH_CHECK("conv_band_kernel");

@@ -38,6 +38,24 @@ struct Conv3Args {
   int Hy, Wy;              // OUT_STRIDE2: full size of y
 };
 
+// "Accumulator" mode of the BatchNorm statistics (optional second kernel argument): instead of per-band partial tiles that a
+// separate finalize launch reduces, the producer conv ADDS its per-band (sum, M2 + n*mean^2) into per-image fp64 accumulators
+// acc[rep = image % nrep][channel][2] with hardware fp64 atomics, and the CONSUMER conv derives the batch statistics and the
+// BatchNorm affine of its input from those accumulators in its own prologue (16 lanes per wave, one channel each).  One
+// launch per BatchNorm layer disappears.  fp64 sums of fp32-precise terms are order-independent up to 1e-16 relative, so the
+// fp32 results are reproducible in practice; Var = (Bq - A^2/n)/n is evaluated in fp64 (no cancellation problem).
+struct BandAcc {
+  double* st_acc;            // producer: accumulators of THIS conv's output statistics, or null
+  const double* in_acc;      // consumer: accumulators of the input's BatchNorm, or null
+  int nrep;                  // replicas (images are spread over them to keep same-address atomics short)
+  int in_target;             // 0: the affine is the (scale, shift) of the activation prologue; 1: it is (kB, kC) of
+                             //    staged = x + in2*kB + kC  (residual sum of the previous block, kA = 1)
+  const float* in_gamma; const float* in_beta;
+  float in_n, in_eps, momentum;
+  float* o_mean; float* o_rstd; float* o_scale; float* o_shift;   // written once (workgroup 0) for the backward pass, may be null
+  float* run_mean; float* run_var;                                 // running statistics (train mode), may be null
+};
+
 // how the epilogue stores the [B,Ho,Wo,Cout] result
 enum : int {
   OUT_NHWC = 0,

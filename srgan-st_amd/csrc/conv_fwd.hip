@@ -25,7 +25,7 @@
 // 64x64-tile variant (conv_fwd2.hip)
 int sst_launch_conv_fwd2(const Conv3Args& a, int stride, hipStream_t st);
 // band kernel for the 64-input-channel trunk shape (conv_band.hip)
-int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st);
+int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st, const BandAcc* acc);
 int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 
 namespace {
@@ -379,7 +379,7 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
                          int Cout, int ksize, int stride, const float* epi_y, const float* epi_scale, const float* epi_shift,
                          const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, void* stream,
                          const float* in2 = nullptr, const float* in_cA = nullptr, const float* in_cB = nullptr,
-                         const float* in_cC = nullptr, float* side_out = nullptr) {
+                         const float* in_cC = nullptr, float* side_out = nullptr, const BandAcc* band_acc = nullptr) {
   SST_REQUIRE(x && wp && y, "sst_conv_fwd: null pointer");
   SST_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 9),
               "sst_conv_fwd: bad shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d stride=%d", B, H, W, Cin, Cout, ksize, stride);
@@ -415,7 +415,7 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   a.dbg = dbg_bits & 15;
   if (out_mode == OUT_NHWC && !(dbg_bits & 8)) {
     const int R = sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride);
-    if (R) return sst_launch_conv_band(a, R, st);
+    if (R) return sst_launch_conv_band(a, R, st, band_acc);
   }
   if (dbg_bits == 0 && use_big_tiles(a, ksize)) return sst_launch_conv_fwd2(a, stride, st);
   if (ksize == 3 && stride == 1)
@@ -496,6 +496,35 @@ SST_API int sst_conv_fwd_resin(const float* x, const float* y2, const float* one
   return conv_fwd_impl(x, wp, y, nullptr, bias, nullptr, nullptr, nullptr, 0.f, ACT_NONE, nullptr, stats, stats_cnt, OUT_NHWC, B, H, W,
                        Cin, Cout, ksize, 1, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, stream, y2, ones, bn_scale, bn_shift,
                        h_out);
+}
+
+// ---- accumulator mode of the BatchNorm statistics (band kernel only, see BandAcc in conv_epilogue.h)
+SST_API int sst_conv_acc_supported(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  return Cin == 64 && sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride) != 0;
+}
+
+// Forward conv in accumulator mode.  Input forms:
+//   in2 == null : staged = act(x*scale + shift)      (scale, shift) from in_acc when given, else no affine
+//   in2 != null : staged = x + in2*scale + shift     (residual sum of the previous block), also written to side_out
+// in_acc / st_acc: fp64 accumulators [nrep][64][2] / [nrep][Cout][2] (st_acc must be zero before the launch); o_* and run_*
+// may be null.  Fails unless sst_conv_acc_supported().
+SST_API int sst_conv_fwd_acc(const float* x, const float* in2, float* side_out, const float* ones, const float* wp, float* y,
+                             const float* bias, const float* in_slope, float in_slope_const, int in_act, const double* in_acc,
+                             const float* in_gamma, const float* in_beta, float in_n, float eps, float momentum, float* o_mean,
+                             float* o_rstd, float* o_scale, float* o_shift, float* run_mean, float* run_var, double* st_acc,
+                             int nrep, int B, int H, int W, int Cin, int Cout, int ksize, void* stream) {
+  SST_REQUIRE(sst_conv_acc_supported(B, H, W, Cin, Cout, ksize, 1), "sst_conv_fwd_acc: shape not covered by the band kernel");
+  SST_REQUIRE(nrep > 0 && (in_acc || st_acc), "sst_conv_fwd_acc: no accumulator given");
+  SST_REQUIRE(!in_acc || (in_gamma && in_beta && in_n > 0.f), "sst_conv_fwd_acc: in_acc needs gamma / beta / n");
+  SST_REQUIRE(!in2 || (side_out && ones), "sst_conv_fwd_acc: residual form needs side_out and the ones vector");
+  BandAcc ba{};
+  ba.st_acc = st_acc; ba.in_acc = in_acc; ba.nrep = nrep; ba.in_target = in2 ? 1 : 0;
+  ba.in_gamma = in_gamma; ba.in_beta = in_beta; ba.in_n = in_n; ba.in_eps = eps; ba.momentum = momentum;
+  ba.o_mean = o_mean; ba.o_rstd = o_rstd; ba.o_scale = o_scale; ba.o_shift = o_shift; ba.run_mean = run_mean; ba.run_var = run_var;
+  // the residual form rides on the fused-input path (kA = ones, kB / kC come from the accumulators inside the kernel)
+  return conv_fwd_impl(x, wp, y, nullptr, bias, nullptr, nullptr, in_slope, in_slope_const, in_act, nullptr, nullptr, nullptr, OUT_NHWC,
+                       B, H, W, Cin, Cout, ksize, 1, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, stream, in2, in2 ? ones : nullptr,
+                       in2 ? ones : nullptr, in2 ? ones : nullptr, side_out, &ba);
 }
 
 // ---- data-gradient of a 3x3 stride-2 pad-1 convolution (Discriminator.features, model.py:35,42,49,56)

@@ -83,31 +83,82 @@ def forward(module, x, params, need_grad):
 
     h = z1
     blocks = []
-    pend = None       # (x, y2, scale2, shift2): the previous block's output h = x + BN2(y2), not materialised yet - the next
-                      # conv forms it while staging its input and hands it back (one bn_residual launch less per block)
-    for i, blk in enumerate(module.trunk):
-        pre = f"trunk.{i}.rcb"
-        first = i == 0
+    B_, H_, W_, _ = z1.shape
+    n_px = float(B_ * H_ * W_)
+    if training and len(module.trunk) and ops.conv_acc_supported(B_, H_, W_, C, C):
+        # ---- accumulator mode: no BatchNorm finalize launches - each conv adds its output statistics into fp64 accumulators and
+        # the NEXT conv derives the affine of its input from them in its prologue (csrc/conv_epilogue.h: BandAcc)
+        nbn = 2 * len(module.trunk) + 1
+        acc = module.__dict__.get("_bn_acc")
+        if acc is None or acc.shape != (nbn, ops.ACC_NREP, C, 2) or acc.device != z1.device:
+            acc = module.__dict__["_bn_acc"] = torch.zeros(nbn, ops.ACC_NREP, C, 2, device=z1.device, dtype=torch.float64)
+        acc.zero_()
+
+        def stat_tensors():
+            return tuple(ops._f32(C, like=z1) for _ in range(4))
+
+        pend = None       # (x, y2, acc2, bn2 module, prefix, (m2, r2, s2, t2)): residual sum formed by the next conv
+        for i, blk in enumerate(module.trunk):
+            pre = f"trunk.{i}.rcb"
+            first = i == 0
+            a_k1, a_k2 = acc[2 * i], acc[2 * i + 1]
+            if pend is None:
+                y1, _ = ops.conv_fwd_acc(h, wp[pre + ".0.weight"], C, 3, in_slope=a1 if first else None,
+                                         in_act=ACT_SLOPE if first else 0, st_acc=a_k1)
+            else:
+                px, py2, pacc, pbn, ppre, pst = pend
+                y1, h = ops.conv_fwd_acc(px, wp[pre + ".0.weight"], C, 3, in2=py2, in_acc=pacc, in_bn=(p[ppre + ".weight"], p[ppre + ".bias"]),
+                                         n=n_px, out_stats=pst, run_stats=(pbn.running_mean, pbn.running_var), st_acc=a_k1)
+            st1 = stat_tensors()
+            y2, _ = ops.conv_fwd_acc(y1, wp[pre + ".3.weight"], C, 3, in_slope=p[pre + ".2.weight"], in_act=ACT_SLOPE, in_acc=a_k1,
+                                     in_bn=(p[pre + ".1.weight"], p[pre + ".1.bias"]), n=n_px, out_stats=st1,
+                                     run_stats=(blk.rcb[1].running_mean, blk.rcb[1].running_var), st_acc=a_k2)
+            if first:     # the skip term is PReLU(z1): stand-alone finalize + residual kernel for this one block
+                st2 = ops.bn_finalize_acc(a_k2, n_px, p[pre + ".4.weight"], p[pre + ".4.bias"], blk.rcb[4].running_mean,
+                                          blk.rcb[4].running_var)
+                blocks.append((h, y1, *st1, y2, *st2))
+                h, pend = ops.bn_residual(y2, st2[2], st2[3], h, a1), None
+            else:
+                st2 = stat_tensors()
+                blocks.append((h, y1, *st1, y2, *st2))
+                pend = (h, y2, a_k2, blk.rcb[4], pre + ".4", st2)
+        a_k3 = acc[nbn - 1]
         if pend is None:
-            y1, _, st, cnt = ops.conv_fwd(h, wp[pre + ".0.weight"], C, 3, 1,
-                                          in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0,
-                                          want_stats=training)
+            y3, _ = ops.conv_fwd_acc(h, wp["conv2.0.weight"], C, 3, st_acc=a_k3)
         else:
-            y1, h, st, cnt = ops.conv_fwd_resin(*pend, wp[pre + ".0.weight"], C, 3, want_stats=training)
-        m1, r1, s1, t1 = bn_affine(blk.rcb[1], pre + ".1", st, cnt)
-        y2, _, st, cnt = ops.conv_fwd(y1, wp[pre + ".3.weight"], C, 3, 1, in_scale=s1, in_shift=t1,
-                                      in_slope=p[pre + ".2.weight"], in_act=ACT_SLOPE, want_stats=training)
-        m2, r2, s2, t2 = bn_affine(blk.rcb[4], pre + ".4", st, cnt)
-        blocks.append((h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2))
-        if first:     # the skip term is PReLU(z1) here: keep the stand-alone residual kernel
-            h, pend = ops.bn_residual(y2, s2, t2, h, a1), None
-        else:
-            pend = (h, y2, s2, t2)
-    if pend is None:
-        y3, _, st, cnt = ops.conv_fwd(h, wp["conv2.0.weight"], C, 3, 1, want_stats=training)
+            px, py2, pacc, pbn, ppre, pst = pend
+            y3, h = ops.conv_fwd_acc(px, wp["conv2.0.weight"], C, 3, in2=py2, in_acc=pacc, in_bn=(p[ppre + ".weight"], p[ppre + ".bias"]),
+                                     n=n_px, out_stats=pst, run_stats=(pbn.running_mean, pbn.running_var), st_acc=a_k3)
+        m3, r3, s3, t3 = ops.bn_finalize_acc(a_k3, n_px, p["conv2.1.weight"], p["conv2.1.bias"], module.conv2[1].running_mean,
+                                             module.conv2[1].running_var)
     else:
-        y3, h, st, cnt = ops.conv_fwd_resin(*pend, wp["conv2.0.weight"], C, 3, want_stats=training)
-    m3, r3, s3, t3 = bn_affine(module.conv2[1], "conv2.1", st, cnt)
+        h = z1
+        blocks = []
+        pend = None       # (x, y2, scale2, shift2): the previous block's output h = x + BN2(y2), not materialised yet - the next
+                          # conv forms it while staging its input and hands it back (one bn_residual launch less per block)
+        for i, blk in enumerate(module.trunk):
+            pre = f"trunk.{i}.rcb"
+            first = i == 0
+            if pend is None:
+                y1, _, st, cnt = ops.conv_fwd(h, wp[pre + ".0.weight"], C, 3, 1,
+                                              in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0,
+                                              want_stats=training)
+            else:
+                y1, h, st, cnt = ops.conv_fwd_resin(*pend, wp[pre + ".0.weight"], C, 3, want_stats=training)
+            m1, r1, s1, t1 = bn_affine(blk.rcb[1], pre + ".1", st, cnt)
+            y2, _, st, cnt = ops.conv_fwd(y1, wp[pre + ".3.weight"], C, 3, 1, in_scale=s1, in_shift=t1,
+                                          in_slope=p[pre + ".2.weight"], in_act=ACT_SLOPE, want_stats=training)
+            m2, r2, s2, t2 = bn_affine(blk.rcb[4], pre + ".4", st, cnt)
+            blocks.append((h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2))
+            if first:     # the skip term is PReLU(z1) here: keep the stand-alone residual kernel
+                h, pend = ops.bn_residual(y2, s2, t2, h, a1), None
+            else:
+                pend = (h, y2, s2, t2)
+        if pend is None:
+            y3, _, st, cnt = ops.conv_fwd(h, wp["conv2.0.weight"], C, 3, 1, want_stats=training)
+        else:
+            y3, h, st, cnt = ops.conv_fwd_resin(*pend, wp["conv2.0.weight"], C, 3, want_stats=training)
+        m3, r3, s3, t3 = bn_affine(module.conv2[1], "conv2.1", st, cnt)
     u = ops.bn_residual(y3, s3, t3, z1, a1)
     sv["blocks"], sv["h_last"], sv["conv2"] = blocks, h, (y3, m3, r3, s3, t3)
     ups = []

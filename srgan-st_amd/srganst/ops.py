@@ -6,6 +6,8 @@ per-kernel parity tests.  No arithmetic happens in Python.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _abi
@@ -133,6 +135,62 @@ def conv_fwd_resin(x, y2, bn_scale, bn_shift, wp, cout, ksize=3, bias=None, want
     _trace(name, flops, lambda: _abi.lib().sst_conv_fwd_resin(*args, stream_ptr()),
            x, y2, ones, bn_scale, bn_shift, h, wp, y, bias, stats, cnt)
     return y, h, stats, cnt
+
+
+ACC_NREP = 16     # replicas of the fp64 BatchNorm accumulators (images are spread over them)
+
+
+def conv_acc_supported(B, H, W, cin, cout, ksize=3, stride=1):
+    return bool(_abi.lib().sst_conv_acc_supported(B, H, W, cin, cout, ksize, stride)) and os.environ.get("SST_ATOMIC_STATS", "1") != "0"
+
+
+def conv_fwd_acc(x, wp, cout, ksize=3, in2=None, bias=None, in_slope=None, in_slope_const=0.0, in_act=ACT_NONE, in_acc=None,
+                 in_bn=None, n=0.0, out_stats=None, run_stats=None, st_acc=None):
+    """Forward conv in accumulator mode (see include/srganst.h: sst_conv_fwd_acc).
+    in_acc: fp64 accumulators of the input's BatchNorm ([ACC_NREP,64,2]) + in_bn = (gamma, beta); out_stats = (mean, rstd, scale,
+    shift) tensors to fill; run_stats = (running_mean, running_var) or None; st_acc: accumulators for this conv's output.
+    in2: residual form (staged = x + in2*scale + shift).  Returns (y, h | None)."""
+    B, H, W, cin = x.shape
+    y = _f32(B, H, W, cout, like=x)
+    h = torch.empty_like(x) if in2 is not None else None
+    ones = None
+    if in2 is not None:
+        key = (x.device, cin)
+        ones = _ONES.get(key)
+        if ones is None:
+            ones = _ONES[key] = torch.ones(cin, device=x.device, dtype=torch.float32)
+    g, bta = in_bn if in_bn is not None else (None, None)
+    om, orr, osc, osh = out_stats if out_stats is not None else (None, None, None, None)
+    rm, rv = run_stats if run_stats is not None else (None, None)
+    args = (ptr(x), ptr(in2), ptr(h), ptr(ones), ptr(wp), ptr(y), ptr(bias), ptr(in_slope), float(in_slope_const), int(in_act),
+            _dptr(in_acc), ptr(g), ptr(bta), float(n), float(BN_EPS), float(BN_MOMENTUM), ptr(om), ptr(orr), ptr(osc), ptr(osh),
+            ptr(rm), ptr(rv), _dptr(st_acc), ACC_NREP, B, H, W, cin, cout, ksize)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv_fwd_acc(*args, stream_ptr()), "sst_conv_fwd_acc")
+    flops = 2.0 * B * H * W * cout * cin * ksize * ksize
+    name = _conv_name(B, H, W, cin, cout, ksize, 1, 0, 1) if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: _abi.lib().sst_conv_fwd_acc(*args, stream_ptr()),
+           x, in2, h, ones, wp, y, bias, in_slope, in_acc, g, bta, om, orr, osc, osh, rm, rv, st_acc)
+    return y, h
+
+
+def _dptr(t):
+    """Device pointer of a contiguous fp64 tensor (accumulators); None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64
+    return t.data_ptr()
+
+
+def bn_finalize_acc(acc, n, gamma, beta, run_mean=None, run_var=None):
+    """bn_finalize from fp64 accumulators [ACC_NREP, C, 2] -> (mean, rstd, scale, shift)."""
+    C = gamma.numel()
+    mean, rstd, scale, shift = (_f32(C, like=gamma) for _ in range(4))
+    check(_abi.lib().sst_bn_finalize_acc(_dptr(acc), acc.shape[0], C, float(n), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_var),
+                                         ptr(mean), ptr(rstd), ptr(scale), ptr(shift), float(BN_EPS), float(BN_MOMENTUM), stream_ptr()),
+          "sst_bn_finalize_acc")
+    return mean, rstd, scale, shift
 
 
 def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,

@@ -128,3 +128,40 @@ def test_generator_eval_and_no_cpu_fallback():
         out = G(x.cuda())
     assert out.shape == (1, 3, 68, 92)
     assert rel_err(out.cpu(), ref) < 1e-4
+
+
+def test_accumulator_mode_equals_partial_tile_mode(monkeypatch):
+    """BatchNorm statistics through fp64 atomic accumulators + consumer-side finalize (csrc/conv_epilogue.h: BandAcc) against
+    the partial-tile + bn_finalize path: same SR, gradients and BatchNorm buffers up to fp32 rounding, over two steps."""
+    from srganst.model import Generator
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst import ops
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(9)
+    gt = torch.rand(4, 3, 96, 96, generator=g).cuda()
+    lr = torch.rand(4, 3, 24, 24, generator=g).cuda()
+    res = {}
+    G0 = Generator(make_cfg(64, 3)).cuda()
+    sd0 = {k: v.clone() for k, v in G0.state_dict().items()}
+    assert ops.conv_acc_supported(4, 24, 24, 64, 64)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SST_ATOMIC_STATS", mode)
+        G = Generator(make_cfg(64, 3)).cuda()
+        G.load_state_dict(sd0)
+        G.train()
+        mse, st = MSELoss(), StructureTensorLoss()
+        out = []
+        for step in range(2):
+            G.zero_grad()
+            sr = G(lr)
+            (mse(sr, gt) + st(sr, gt) * (1 / 3)).backward()
+            out.append((sr.detach().cpu(), {n: p.grad.cpu().clone() for n, p in G.named_parameters()},
+                        {k: v.cpu().clone() for k, v in G.state_dict().items() if "running" in k}))
+        res[mode] = out
+    for (sr_a, gr_a, bn_a), (sr_b, gr_b, bn_b) in zip(res["1"], res["0"]):
+        assert rel_err(sr_a, sr_b) < 1e-5
+        for n in gr_a:
+            tol = 1e-3 if gr_a[n].numel() == 1 else 2e-4      # scalar slope gradients are cancelling sums
+            assert rel_err(gr_a[n], gr_b[n]) < tol, n
+        for k in bn_a:
+            assert torch.allclose(bn_a[k], bn_b[k], rtol=1e-5, atol=1e-7), k

@@ -29,3 +29,18 @@ for band in ("3", "9", "0"):
     t = timeit(lambda: ops.conv_dgrad_fused(x, y2, wd, C, 3, cA=cA, cB=cB, cC=cC, in_scale=sc, in_shift=sh, in_slope_const=0.2, in_act=1,
                                             residual=res, epi_y=ys, epi_scale=sc, epi_shift=sh, epi_slope_const=0.2, epi_act=1))
     print(f"   {'fused bwd stage':14s} {t:8.1f} us   {flops/t/1e6:7.1f} TF/s")
+
+# ---- accumulator mode (fp64 atomics in the epilogue, BN affine from accumulators in the prologue)
+os.environ["SST_CONV_BAND"] = "3"
+acc_in = torch.rand(ops.ACC_NREP, C, 2, device="cuda", dtype=torch.float64) + 1.0
+acc_in[..., 1] += 50.0
+acc_out = torch.zeros(ops.ACC_NREP, C, 2, device="cuda", dtype=torch.float64)
+gam, bet = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+outs = tuple(torch.empty(C, device="cuda") for _ in range(4))
+n = float(B * H * W)
+print("accumulator mode, NB=3")
+print("   plain fwd (reference point)  %.1f us" % timeit(lambda: ops.conv_fwd(x, wp, C, 3, 1)))
+print("   fwd + bn prologue + stats    %.1f us" % timeit(lambda: ops.conv_fwd(x, wp, C, 3, 1, in_scale=sc, in_shift=sh, in_slope_const=0.2, in_act=1, want_stats=True)))
+print("   producer only (atomics)      %.1f us" % timeit(lambda: ops.conv_fwd_acc(x, wp, C, 3, in_slope_const=0.2, in_act=1, st_acc=acc_out)))
+print("   consumer only (acc prologue) %.1f us" % timeit(lambda: ops.conv_fwd_acc(x, wp, C, 3, in_slope_const=0.2, in_act=1, in_acc=acc_in, in_bn=(gam, bet), n=n, out_stats=outs)))
+print("   both                         %.1f us" % timeit(lambda: ops.conv_fwd_acc(x, wp, C, 3, in_slope_const=0.2, in_act=1, in_acc=acc_in, in_bn=(gam, bet), n=n, out_stats=outs, st_acc=acc_out)))
