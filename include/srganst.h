@@ -85,6 +85,16 @@ int sst_conv_fwd_acc(const float* x, const float* in2, float* side_out, const fl
                      const float* in_gamma, const float* in_beta, float in_n, float eps, float momentum, float* o_mean,
                      float* o_rstd, float* o_scale, float* o_shift, float* run_mean, float* run_var, double* st_acc,
                      int nrep, int B, int H, int W, int Cin, int Cout, int ksize, void* stream);
+/* one BatchNorm-backward stage in accumulator mode: coefficients from bw_in_acc [nrep][64][4] + mean/rstd/gamma (prologue),
+ * next stage's sums added into bw_st_acc [nrep][Cout][4] (epilogue); dgamma/dbeta/dslope written once.  Replaces the
+ * sst_bwd_finalize launch between two sst_conv_dgrad_fused stages. */
+int sst_conv_dgrad_fused_acc(const float* g, const float* y2, const float* in_scale, const float* in_shift,
+                             const float* in_slope, float in_slope_const, int in_act, float* dy_out, const float* wp,
+                             float* out, const float* residual, const float* epi_y, const float* epi_scale,
+                             const float* epi_shift, const float* epi_slope, float epi_slope_const, int epi_act,
+                             const double* bw_in_acc, const float* mean, const float* rstd, const float* gamma, float n,
+                             float* dgamma, float* dbeta, float* dslope, double* bw_st_acc, int nrep, int B, int H,
+                             int W, int Cin, int Cout, int ksize, void* stream);
 int sst_bn_finalize_acc(const double* acc, int nrep, int C, float n, const float* gamma, const float* beta,
                         float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
                         float eps, float momentum, void* stream);

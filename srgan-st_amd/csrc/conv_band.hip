@@ -36,7 +36,8 @@ template <int NB>
 __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(Conv3Args a, int R, int nbands, BandAcc ba) {   // NB = 3: keep 3 workgroups per CU (<= 168 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sstat[4][3][16];
-  __shared__ float saff[4][2][16];
+  __shared__ float saff[4][3][16];
+  __shared__ float sslope[4];
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int W = a.W, PW = W + 2, npatch = (R + 2) * PW;
@@ -124,6 +125,57 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
       else { kB = s4; kC = t4; have_k = true; }
     };
     if (ba.in_acc) affine_from_acc();
+    if (ba.bw_in_acc) {
+      // BatchNorm-backward coefficients of the input from the producer's accumulators [nrep][64][4] (same lane mapping)
+      double S0 = 0.0, S1 = 0.0, S2 = 0.0;
+      {
+        const int ch = wave * 16 + (lane & 15), part = lane >> 4;
+        f64x2 v0[MAXR / 2], v1[MAXR / 2];
+#pragma unroll
+        for (int k = 0; k < MAXR / 2; ++k) {                 // nrep <= 16 here
+          const int r = part + 4 * k;
+          v0[k] = v1[k] = f64x2{0.0, 0.0};
+          if (r < ba.nrep) {
+            const double* q = ba.bw_in_acc + ((size_t)r * 64 + ch) * 4;
+            v0[k] = *reinterpret_cast<const f64x2*>(q);
+            v1[k] = *reinterpret_cast<const f64x2*>(q + 2);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXR / 2; ++k) { S0 += v0[k][0]; S1 += v0[k][1]; S2 += v1[k][0]; }
+        S0 += __shfl_xor(S0, 16, 64); S1 += __shfl_xor(S1, 16, 64); S2 += __shfl_xor(S2, 16, 64);
+        S0 += __shfl_xor(S0, 32, 64); S1 += __shfl_xor(S1, 32, 64); S2 += __shfl_xor(S2, 32, 64);
+      }
+      const bool pub = blockIdx.x == 0 && blockIdx.y == 0;
+      float s2f = 0.f;
+      if (lane < 16) {
+        const int ch = wave * 16 + lane;
+        const float mu = ba.bw_mean[ch], rs = ba.bw_rstd[ch], ga = ba.bw_gamma[ch];
+        const float s0 = (float)S0, s1 = (float)S1;
+        const float sgh = rs * (s1 - mu * s0);               // same arithmetic as bwd_finalize2_kernel
+        const float m1 = s0 / ba.bw_n, m2 = sgh / ba.bw_n;
+        const float aa = ga * rs;
+        saff[wave][0][lane] = aa;
+        saff[wave][1][lane] = -aa * rs * m2;
+        saff[wave][2][lane] = -aa * m1 + aa * rs * mu * m2;
+        if (pub) { ba.o_dgamma[ch] = sgh; ba.o_dbeta[ch] = s0; }
+        s2f = (float)S2;
+      }
+      if (pub && ba.o_dslope) {                              // scalar slope gradient: sum over all 64 channels, fixed order
+        s2f += __shfl_xor(s2f, 1, 64); s2f += __shfl_xor(s2f, 2, 64); s2f += __shfl_xor(s2f, 4, 64); s2f += __shfl_xor(s2f, 8, 64);
+        if (lane == 0) sslope[wave] = s2f;
+        __syncthreads();                                     // workgroup-uniform condition
+        if (tid == 0) ba.o_dslope[0] = ((sslope[0] + sslope[1]) + sslope[2]) + sslope[3];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kA[j] = saff[wave][0][q4 + j];
+        kB[j] = saff[wave][1][q4 + j];
+        kC[j] = saff[wave][2][q4 + j];
+      }
+      have_k = true;
+    }
     const float* xb = a.x + (size_t)b * a.H * W * 64 + c;
     const float* x2b = a.in2 ? a.in2 + (size_t)b * a.H * W * 64 + c : nullptr;
     float* sob = (a.side_out && g == 0) ? a.side_out + (size_t)b * a.H * W * 64 + c : nullptr;
@@ -319,7 +371,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     }
   }
 
-  if (a.epi_partial) {
+  if (a.epi_partial || ba.bw_st_acc) {
     // backward partials of the stored g against epi_y (see Conv3Args): sums of (gz, gz*y, g*min(z,0)) over the band
     const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
     f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
@@ -362,7 +414,9 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     __syncthreads();
     if (tid < 48) {
       const int k = tid >> 4, c = tid & 15;
-      a.epi_partial[((size_t)mt * 3 + k) * a.Cout + g * 16 + c] = sstat[0][k][c] + sstat[1][k][c] + sstat[2][k][c] + sstat[3][k][c];
+      const float t = sstat[0][k][c] + sstat[1][k][c] + sstat[2][k][c] + sstat[3][k][c];
+      if (a.epi_partial) a.epi_partial[((size_t)mt * 3 + k) * a.Cout + g * 16 + c] = t;
+      if (ba.bw_st_acc) __builtin_amdgcn_global_atomic_fadd_f64(ba.bw_st_acc + ((size_t)(b % ba.nrep) * a.Cout + g * 16 + c) * 4 + k, (double)t);
     }
   }
 }

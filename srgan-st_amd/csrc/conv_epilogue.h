@@ -54,6 +54,14 @@ struct BandAcc {
   float in_n, in_eps, momentum;
   float* o_mean; float* o_rstd; float* o_scale; float* o_shift;   // written once (workgroup 0) for the backward pass, may be null
   float* run_mean; float* run_var;                                 // running statistics (train mode), may be null
+  // ---- backward: the BatchNorm/activation backward partial sums (sum gz, sum gz*y, sum g*min(z,0)) the same way:
+  // producer adds its per-band sums into bw_st_acc[nrep][Cout][4] (4th word unused), the consumer derives the coefficients of
+  //   dy = cA*gz + cB*y + cC   from bw_in_acc + (mean, rstd, gamma) in its prologue and publishes dgamma / dbeta / dslope once.
+  double* bw_st_acc;
+  const double* bw_in_acc;
+  const float* bw_mean; const float* bw_rstd; const float* bw_gamma;
+  float bw_n;
+  float* o_dgamma; float* o_dbeta; float* o_dslope;                // o_dslope may be null (BatchNorm without activation)
 };
 
 // how the epilogue stores the [B,Ho,Wo,Cout] result

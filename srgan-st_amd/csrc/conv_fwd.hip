@@ -527,6 +527,33 @@ SST_API int sst_conv_fwd_acc(const float* x, const float* in2, float* side_out, 
                        in2 ? ones : nullptr, in2 ? ones : nullptr, side_out, &ba);
 }
 
+// One BatchNorm-backward stage in accumulator mode (see sst_conv_dgrad_fused for the arithmetic): the coefficients of
+//   dy = cA*gz + cB*y2 + cC   come from bw_in_acc [nrep][64][4] (sums added by the PREVIOUS stage's epilogue) + mean / rstd /
+// gamma, and this stage's epilogue adds the next stage's sums into bw_st_acc [nrep][Cout][4] (zero before the launch).
+// y2 == null: plain data-gradient of g (no BatchNorm-backward apply on the input; bw_in_acc must be null).
+// dgamma / dbeta [64] (and dslope [1] when non-null) of the applied BatchNorm are written once.
+SST_API int sst_conv_dgrad_fused_acc(const float* g, const float* y2, const float* in_scale, const float* in_shift, const float* in_slope,
+                                     float in_slope_const, int in_act, float* dy_out, const float* wp, float* out,
+                                     const float* residual, const float* epi_y, const float* epi_scale, const float* epi_shift,
+                                     const float* epi_slope, float epi_slope_const, int epi_act, const double* bw_in_acc,
+                                     const float* mean, const float* rstd, const float* gamma, float n, float* dgamma, float* dbeta,
+                                     float* dslope, double* bw_st_acc, int nrep, int B, int H, int W, int Cin, int Cout, int ksize,
+                                     void* stream) {
+  SST_REQUIRE(sst_conv_acc_supported(B, H, W, Cin, Cout, ksize, 1), "sst_conv_dgrad_fused_acc: shape not covered by the band kernel");
+  SST_REQUIRE(nrep > 0 && nrep <= 16 && (bw_in_acc || bw_st_acc), "sst_conv_dgrad_fused_acc: no accumulator given / nrep > 16");
+  SST_REQUIRE(!bw_in_acc || (y2 && dy_out && mean && rstd && gamma && dgamma && dbeta && n > 0.f),
+              "sst_conv_dgrad_fused_acc: bw_in_acc needs y2 / dy_out / mean / rstd / gamma / dgamma / dbeta / n");
+  SST_REQUIRE(!bw_st_acc || epi_y, "sst_conv_dgrad_fused_acc: bw_st_acc needs epi_y");
+  SST_REQUIRE(!y2 || dy_out, "sst_conv_dgrad_fused_acc: y2 needs dy_out");
+  BandAcc ba{};
+  ba.nrep = nrep;
+  ba.bw_st_acc = bw_st_acc; ba.bw_in_acc = bw_in_acc; ba.bw_mean = mean; ba.bw_rstd = rstd; ba.bw_gamma = gamma; ba.bw_n = n;
+  ba.o_dgamma = dgamma; ba.o_dbeta = dbeta; ba.o_dslope = dslope;
+  return conv_fwd_impl(g, wp, out, nullptr, nullptr, in_scale, in_shift, in_slope, in_slope_const, in_act, residual, nullptr, nullptr,
+                       OUT_NHWC, B, H, W, Cin, Cout, ksize, 1, epi_y, epi_scale, epi_shift, epi_slope, epi_slope_const, epi_act, nullptr,
+                       stream, y2, nullptr, nullptr, nullptr, y2 ? dy_out : nullptr, &ba);
+}
+
 // ---- data-gradient of a 3x3 stride-2 pad-1 convolution (Discriminator.features, model.py:35,42,49,56)
 SST_API int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin) { return s2_class_offset(4, Cin, Cout); }
 

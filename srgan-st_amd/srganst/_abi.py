@@ -41,6 +41,8 @@ SIGNATURES = {
     "sst_conv_acc_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_fwd_acc": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_float, c_float, c_float, P, P, P, P, P, P, P,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_dgrad_fused_acc": (c_int, [P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_float, P, P, P,
+                                         P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_bn_finalize_acc": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, c_float, c_float, P]),
     "sst_conv_fwd_resin": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_dgrad_bwdstats": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -228,30 +228,58 @@ def backward(module, params, sv, dsr, need_dx=False):
            in_slope=a1 if not sv["blocks"] else None, in_act=ACT_SLOPE if not sv["blocks"] else 0)
     dskip = g
     nb = len(sv["blocks"])
-    # every stride-1 data-gradient conv below also emits the BatchNorm-backward partial sums of its result against the
-    # conv output the NEXT backward stage differentiates through (saves one reduction pass per stage)
-    if nb:
-        dh, part = ops.conv_dgrad_bwdstats(dy3, wd["conv2.0.weight"], C, 3, sv["blocks"][-1][6])        # vs y2 of the last block
+    Bq, Hq, Wq, _ = y3.shape
+    if nb and ops.conv_acc_supported(Bq, Hq, Wq, C, C):
+        # ---- accumulator mode: every data-gradient conv adds the BatchNorm-backward sums of its result into fp64 accumulators,
+        # the next stage derives its coefficients from them in its prologue (no finalize launches between the stages)
+        bacc = module.__dict__.get("_bn_bw_acc")
+        if bacc is None or bacc.shape != (2 * nb, ops.ACC_NREP, C, 4) or bacc.device != y3.device:
+            bacc = module.__dict__["_bn_bw_acc"] = torch.zeros(2 * nb, ops.ACC_NREP, C, 4, device=y3.device, dtype=torch.float64)
+        bacc.zero_()
+        dh, _ = ops.conv_dgrad_fused_acc(dy3, wd["conv2.0.weight"], C, 3, epi_y=sv["blocks"][-1][6], bw_st_acc=bacc[2 * nb - 1])
+        for i in reversed(range(nb)):
+            pre = f"trunk.{i}.rcb"
+            first = i == 0
+            h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2 = sv["blocks"][i]
+            sl = p[pre + ".2.weight"]
+            # stage 2 (BN2, no activation): [coefficients + apply + dgrad conv_b + sums for stage 1] in one launch
+            dp1, dy2 = ops.conv_dgrad_fused_acc(dh, wd[pre + ".3.weight"], C, 3, y2=y2, epi_y=y1, epi_scale=s1, epi_shift=t1, epi_slope=sl,
+                                                epi_act=1, bw_in_acc=bacc[2 * i + 1], bn=(m2, r2, p[pre + ".4.weight"]), n=n,
+                                                dgamma=grads[pre + ".4.weight"], dbeta=grads[pre + ".4.bias"], bw_st_acc=bacc[2 * i])
+            wg.add(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
+            # stage 1 (BN1 + PReLU)
+            prev_y2 = None if first else sv["blocks"][i - 1][6]
+            dh, dy1 = ops.conv_dgrad_fused_acc(dp1, wd[pre + ".0.weight"], C, 3, y2=y1, in_scale=s1, in_shift=t1, in_slope=sl,
+                                               in_act=ACT_SLOPE, residual=dh, epi_y=prev_y2, bw_in_acc=bacc[2 * i],
+                                               bn=(m1, r1, p[pre + ".1.weight"]), n=n, dgamma=grads[pre + ".1.weight"],
+                                               dbeta=grads[pre + ".1.bias"], dslope=grads[pre + ".2.weight"],
+                                               bw_st_acc=None if first else bacc[2 * i - 1])
+            wg.add(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0)
     else:
-        dh, part = ops.conv_fwd(dy3, wd["conv2.0.weight"], C, 3, 1)[0], None
-    # ---- residual blocks, last to first
-    for i in reversed(range(nb)):
-        pre = f"trunk.{i}.rcb"
-        first = i == 0
-        h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2 = sv["blocks"][i]
-        sl = p[pre + ".2.weight"]
-        # stage 2 (BN2, no activation): finalize -> [apply + dgrad conv_b + partials for stage 1] in one launch
-        cA, cB, cC = ops.bwd_finalize(part, n, m2, r2, p[pre + ".4.weight"], grads[pre + ".4.weight"], grads[pre + ".4.bias"])
-        dp1, dy2, part = ops.conv_dgrad_fused(dh, y2, wd[pre + ".3.weight"], C, 3, cA, cB, cC, epi_y=y1, epi_scale=s1,
-                                              epi_shift=t1, epi_slope=sl, epi_act=1)
-        wg.add(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
-        # stage 1 (BN1 + PReLU)
-        cA, cB, cC = ops.bwd_finalize(part, n, m1, r1, p[pre + ".1.weight"], grads[pre + ".1.weight"], grads[pre + ".1.bias"],
-                                      dslope=grads[pre + ".2.weight"])
-        prev_y2 = None if first else sv["blocks"][i - 1][6]
-        dh, dy1, part = ops.conv_dgrad_fused(dp1, y1, wd[pre + ".0.weight"], C, 3, cA, cB, cC, in_scale=s1, in_shift=t1,
-                                             in_slope=sl, in_act=ACT_SLOPE, residual=dh, epi_y=prev_y2)
-        wg.add(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0)
+        # every stride-1 data-gradient conv below also emits the BatchNorm-backward partial sums of its result against the
+        # conv output the NEXT backward stage differentiates through (saves one reduction pass per stage)
+        if nb:
+            dh, part = ops.conv_dgrad_bwdstats(dy3, wd["conv2.0.weight"], C, 3, sv["blocks"][-1][6])        # vs y2 of the last block
+        else:
+            dh, part = ops.conv_fwd(dy3, wd["conv2.0.weight"], C, 3, 1)[0], None
+        # ---- residual blocks, last to first
+        for i in reversed(range(nb)):
+            pre = f"trunk.{i}.rcb"
+            first = i == 0
+            h, y1, m1, r1, s1, t1, y2, m2, r2, s2, t2 = sv["blocks"][i]
+            sl = p[pre + ".2.weight"]
+            # stage 2 (BN2, no activation): finalize -> [apply + dgrad conv_b + partials for stage 1] in one launch
+            cA, cB, cC = ops.bwd_finalize(part, n, m2, r2, p[pre + ".4.weight"], grads[pre + ".4.weight"], grads[pre + ".4.bias"])
+            dp1, dy2, part = ops.conv_dgrad_fused(dh, y2, wd[pre + ".3.weight"], C, 3, cA, cB, cC, epi_y=y1, epi_scale=s1,
+                                                  epi_shift=t1, epi_slope=sl, epi_act=1)
+            wg.add(y1, dy2, grads[pre + ".3.weight"], 3, 1, in_scale=s1, in_shift=t1, in_slope=sl, in_act=ACT_SLOPE)
+            # stage 1 (BN1 + PReLU)
+            cA, cB, cC = ops.bwd_finalize(part, n, m1, r1, p[pre + ".1.weight"], grads[pre + ".1.weight"], grads[pre + ".1.bias"],
+                                          dslope=grads[pre + ".2.weight"])
+            prev_y2 = None if first else sv["blocks"][i - 1][6]
+            dh, dy1, part = ops.conv_dgrad_fused(dp1, y1, wd[pre + ".0.weight"], C, 3, cA, cB, cC, in_scale=s1, in_shift=t1,
+                                                 in_slope=sl, in_act=ACT_SLOPE, residual=dh, epi_y=prev_y2)
+            wg.add(h, dy1, grads[pre + ".0.weight"], 3, 1, in_slope=a1 if first else None, in_act=ACT_SLOPE if first else 0)
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
     dz1 = ops.act_bwd(dh, z1, g2=dskip, slope=a1, dbias=grads["conv1.0.bias"], dslope=grads["conv1.1.weight"])

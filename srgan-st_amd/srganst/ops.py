@@ -175,6 +175,30 @@ def conv_fwd_acc(x, wp, cout, ksize=3, in2=None, bias=None, in_slope=None, in_sl
     return y, h
 
 
+def conv_dgrad_fused_acc(g, wd, cout, ksize=3, y2=None, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0, in_act=0,
+                         residual=None, epi_y=None, epi_scale=None, epi_shift=None, epi_slope=None, epi_slope_const=0.0, epi_act=0,
+                         bw_in_acc=None, bn=None, n=0.0, dgamma=None, dbeta=None, dslope=None, bw_st_acc=None):
+    """One BatchNorm-backward stage in accumulator mode (include/srganst.h: sst_conv_dgrad_fused_acc).  bn = (mean, rstd, gamma)
+    of the BatchNorm being differentiated; returns (out, dy | None)."""
+    B, H, W, cin = g.shape
+    out = _f32(B, H, W, cout, like=g)
+    dy = torch.empty_like(g) if y2 is not None else None
+    mean, rstd, gamma = bn if bn is not None else (None, None, None)
+    args = (ptr(g), ptr(y2), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const), int(in_act), ptr(dy), ptr(wd), ptr(out),
+            ptr(residual), ptr(epi_y), ptr(epi_scale), ptr(epi_shift), ptr(epi_slope), float(epi_slope_const), int(epi_act),
+            _dptr(bw_in_acc), ptr(mean), ptr(rstd), ptr(gamma), float(n), ptr(dgamma), ptr(dbeta), ptr(dslope), _dptr(bw_st_acc),
+            ACC_NREP, B, H, W, cin, cout, ksize)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv_dgrad_fused_acc(*args, stream_ptr()), "sst_conv_dgrad_fused_acc")
+    flops = 2.0 * B * H * W * cout * cin * ksize * ksize
+    name = _conv_name(B, H, W, cin, cout, ksize, 1, 0, 1) if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: _abi.lib().sst_conv_dgrad_fused_acc(*args, stream_ptr()),
+           g, y2, in_scale, in_shift, in_slope, dy, wd, out, residual, epi_y, epi_scale, epi_shift, epi_slope, bw_in_acc, mean, rstd, gamma,
+           dgamma, dbeta, dslope, bw_st_acc)
+    return out, dy
+
+
 def _dptr(t):
     """Device pointer of a contiguous fp64 tensor (accumulators); None -> NULL."""
     if t is None:
