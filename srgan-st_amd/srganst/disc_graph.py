@@ -61,7 +61,20 @@ def forward(module, x, p, training):
 def backward(module, p, sv, dout, need_param_grads, need_dx):
     grads = {}
     names = list(p.keys())
-    views = ops.flat_grads(module, names, [p[n] for n in names]) if need_param_grads else {}
+    # Two backward passes per D step (D(gt) and D(sr), train.py:155-161): when the step engine opened an accumulation scope
+    # (module._grad_accum), the second pass ADDS into the first pass's flat buffer with the kernels' accumulate flag and hands
+    # autograd nothing - p.grad stays a view of ONE flat buffer (flat Adam, single RCCL message) and autograd's own
+    # out-of-place sum of two 94 MB gradient sets disappears.
+    scope = module.__dict__.get("_grad_accum") if need_param_grads else None
+    acc = scope is not None and scope.get("flat") is not None
+    if acc:
+        plist = [p[n] for n in names]
+        offs, _ = ops.flat_layout(plist)
+        views = {n: scope["flat"][o:o + t.numel()].view(t.shape) for n, t, o in zip(names, plist, offs)}
+    else:
+        views = ops.flat_grads(module, names, [p[n] for n in names]) if need_param_grads else {}
+        if scope is not None:
+            scope["flat"] = module.__dict__["_flat_grads"][-1]
 
     def G(name):
         t = views[name]
@@ -71,11 +84,11 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
     h1, flat = sv["h1"], sv["flat"]
     wg = need_param_grads
     dh1 = ops.head_bwd(h1, p["classifier.2.weight"], dout.contiguous(), LRELU,
-                       dw=G("classifier.2.weight") if wg else None, db=G("classifier.2.bias") if wg else None)
+                       dw=G("classifier.2.weight") if wg else None, db=G("classifier.2.bias") if wg else None, accumulate=acc)
     if wg:
         dw0, db0 = G("classifier.0.weight"), G("classifier.0.bias")
         with ops.SideStream(dh1, flat, dw0, db0):
-            ops.linear_wgrad(dh1, flat, dw0, db0)
+            ops.linear_wgrad(dh1, flat, dw0, db0, accumulate=acc)
     last = sv["layers"][-1]
     B, H, W, C = last["y"].shape
     g = ops.linear_dgrad(dh1, p["classifier.0.weight"], nhwc=(C, H * W)).view(B, H, W, C)   # d LReLU(BN(y_last)) in NHWC
@@ -93,10 +106,10 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
             dg = G(f"features.{bi}.weight") if wg else torch.empty_like(gam)
             db = G(f"features.{bi}.bias") if wg else torch.empty_like(gam)
             kw = dict(scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1, mean=r["mean"], rstd=r["rstd"], gamma=gam,
-                      dgamma=dg, dbeta=db)
+                      dgamma=dg, dbeta=db, accumulate=acc and wg)
             dy = ops.bwd_finalize_apply(part, g, y, n, **kw) if part is not None else ops.bwd_reduce_apply(g, y, n, **kw)
         elif wg:
-            kw = dict(slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"))
+            kw = dict(slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"), accumulate=acc)
             dy = ops.bwd_finalize_apply(part, g, y, n, **kw) if part is not None else ops.bwd_reduce_apply(g, y, n, **kw)
         else:
             dy = ops.bwd_apply(g, y, slope_const=LRELU, act=1)
@@ -105,7 +118,7 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
             dwc = G(f"features.{ci}.weight")
             with ops.SideStream(r["x"], dy, dwc):
                 ops.conv_wgrad(r["x"], dy, dwc, 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
-                               in_slope_const=LRELU, in_act=r["x_act"])
+                               in_slope_const=LRELU, in_act=r["x_act"], accumulate=acc)
         if li == 0 and not need_dx:
             break
         xin = r["x"]
@@ -122,6 +135,8 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
         if li == 0:
             dx = ops.transpose(g, to_nchw=True)
     ops.join_side()
+    if acc:
+        grads = {}                   # already added into the first pass's buffer
     return grads, dx
 
 

@@ -211,7 +211,11 @@ class TrainEngine:
         pred_sr = self.D(self.sr.detach().clone())
         loss_fake = self.adv(pred_sr, self.fake)
         d_loss = loss_real + loss_fake
-        d_loss.backward()
+        self.D.__dict__["_grad_accum"] = {"flat": None}      # both backward passes write ONE flat gradient buffer (disc_graph.backward)
+        try:
+            d_loss.backward()
+        finally:
+            self.D.__dict__.pop("_grad_accum", None)
         self.d_loss, self.pred_gt, self.pred_sr = d_loss.detach(), pred_gt.detach(), pred_sr.detach()
         return self.d_loss
 
