@@ -38,6 +38,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
   __shared__ float sstat[4][3][16];
   __shared__ float saff[4][3][16];
   __shared__ float sslope[4];
+  __shared__ double ssq[4][16];
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int W = a.W, PW = W + 2, npatch = (R + 2) * PW;
@@ -326,47 +327,47 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
   };
 
   if (a.stats || ba.st_acc) {
-    // per-band (sum, centred M2) per output channel
+    // per-band (sum, sum of squares) per output channel in ONE pass: the squares are accumulated in fp64, so the centred
+    // M2 = q - sum^2/n (partial-tile mode) and Chan's combination (accumulator mode adds q itself) lose nothing to
+    // cancellation, and the second pass over the values with its extra barrier is gone
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < MYB; ++i) s1 += v[i];
+    for (int i = 0; i < MYB; ++i) {
+      s1 += v[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s1[j] = reduce16(s1[j]);
-    if (lp16 == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sstat[wave][0][4 * lj + j] = s1[j];
+      for (int j = 0; j < 4; ++j) q[j] = fma((double)v[i][j], (double)v[i][j], q[j]);     // v is 0 where !have
     }
-    __syncthreads();
-    f32x4 m2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int ch = 4 * lj + j;
-      const float mean = (sstat[0][0][ch] + sstat[1][0][ch] + sstat[2][0][ch] + sstat[3][0][ch]) / (float)npx;
-#pragma unroll
-      for (int i = 0; i < MYB; ++i) {
-        const float d = have[i] ? v[i][j] - mean : 0.f;
-        m2[j] = fmaf(d, d, m2[j]);
-      }
-      m2[j] = reduce16(m2[j]);
+      s1[j] = reduce16(s1[j]);
+      q[j] += __shfl_xor(q[j], 1, 64);
+      q[j] += __shfl_xor(q[j], 2, 64);
+      q[j] += __shfl_xor(q[j], 4, 64);
+      q[j] += __shfl_xor(q[j], 8, 64);
     }
     if (lp16 == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sstat[wave][1][4 * lj + j] = m2[j];
+      for (int j = 0; j < 4; ++j) {
+        sstat[wave][0][4 * lj + j] = s1[j];
+        ssq[wave][4 * lj + j] = q[j];
+      }
     }
     __syncthreads();
     if (tid < 16) {
       const float tot = sstat[0][0][tid] + sstat[1][0][tid] + sstat[2][0][tid] + sstat[3][0][tid];
-      const float m2t = sstat[0][1][tid] + sstat[1][1][tid] + sstat[2][1][tid] + sstat[3][1][tid];
+      const double qt = ((ssq[0][tid] + ssq[1][tid]) + ssq[2][tid]) + ssq[3][tid];
       if (a.stats) {
         float* st = a.stats + (size_t)mt * 2 * a.Cout + g * 16 + tid;
+        const double m2 = qt - (double)tot * (double)tot / (double)npx;
         st[0] = tot;
-        st[a.Cout] = m2t;
+        st[a.Cout] = (float)(m2 > 0.0 ? m2 : 0.0);
         if (tid == 0 && g == 0) a.stats_cnt[mt] = (float)npx;
       }
-      if (ba.st_acc) {      // A += sum, Bq += M2 + n_b * mean_b^2   (fp64 hardware atomics, no return value needed)
+      if (ba.st_acc) {      // A += sum, Bq += sum of squares   (fp64 hardware atomics, no return value needed)
         double* p = ba.st_acc + ((size_t)(b % ba.nrep) * a.Cout + g * 16 + tid) * 2;
         __builtin_amdgcn_global_atomic_fadd_f64(p, (double)tot);
-        __builtin_amdgcn_global_atomic_fadd_f64(p + 1, (double)m2t + (double)tot * (double)tot / (double)npx);
+        __builtin_amdgcn_global_atomic_fadd_f64(p + 1, qt);
       }
     }
   }
