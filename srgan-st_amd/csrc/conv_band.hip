@@ -78,8 +78,11 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     constexpr int MAXR = 8;                                 // replicas per lane (nrep <= 32)
     f64x2 accv[MAXR];
+    float pre_g = 0.f, pre_b = 0.f;                       // gamma / beta of the lane's channel: in flight with the accumulators
     if (ba.in_acc) {
       const int ch = wave * 16 + (lane & 15), part = lane >> 4;
+      pre_g = ba.in_gamma[ch];
+      pre_b = ba.in_beta[ch];
 #pragma unroll
       for (int k = 0; k < MAXR; ++k) {
         const int r = part + 4 * k;
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
         if (m2 < 0.0) m2 = 0.0;
         const float var = (float)(m2 / n);
         const float rstd = 1.f / sqrtf(var + ba.in_eps);
-        const float scv = ba.in_gamma[ch] * rstd;
-        const float shv = ba.in_beta[ch] - (float)mean * scv;
+        const float scv = pre_g * rstd;
+        const float shv = pre_b - (float)mean * scv;
         saff[wave][0][lane] = scv;
         saff[wave][1][lane] = shv;
         if (blockIdx.x == 0 && blockIdx.y == 0) {          // one workgroup publishes the statistics for the backward pass
@@ -129,6 +132,8 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     if (ba.bw_in_acc) {
       // BatchNorm-backward coefficients of the input from the producer's accumulators [nrep][64][4] (same lane mapping)
       double S0 = 0.0, S1 = 0.0, S2 = 0.0;
+      const float mu = ba.bw_mean[wave * 16 + (lane & 15)], rs = ba.bw_rstd[wave * 16 + (lane & 15)],
+                  ga = ba.bw_gamma[wave * 16 + (lane & 15)];          // in flight with the accumulator loads
       {
         const int ch = wave * 16 + (lane & 15), part = lane >> 4;
         f64x2 v0[MAXR / 2], v1[MAXR / 2];
@@ -151,7 +156,6 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
       float s2f = 0.f;
       if (lane < 16) {
         const int ch = wave * 16 + lane;
-        const float mu = ba.bw_mean[ch], rs = ba.bw_rstd[ch], ga = ba.bw_gamma[ch];
         const float s0 = (float)S0, s1 = (float)S1;
         const float sgh = rs * (s1 - mu * s0);               // same arithmetic as bwd_finalize2_kernel
         const float m1 = s0 / ba.bw_n, m2 = sgh / ba.bw_n;

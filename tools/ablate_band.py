@@ -44,3 +44,12 @@ print("   fwd + bn prologue + stats    %.1f us" % timeit(lambda: ops.conv_fwd(x,
 print("   producer only (atomics)      %.1f us" % timeit(lambda: ops.conv_fwd_acc(x, wp, C, 3, in_slope_const=0.2, in_act=1, st_acc=acc_out)))
 print("   consumer only (acc prologue) %.1f us" % timeit(lambda: ops.conv_fwd_acc(x, wp, C, 3, in_slope_const=0.2, in_act=1, in_acc=acc_in, in_bn=(gam, bet), n=n, out_stats=outs)))
 print("   both                         %.1f us" % timeit(lambda: ops.conv_fwd_acc(x, wp, C, 3, in_slope_const=0.2, in_act=1, in_acc=acc_in, in_bn=(gam, bet), n=n, out_stats=outs, st_acc=acc_out)))
+bacc_in = torch.rand(ops.ACC_NREP, C, 4, device="cuda", dtype=torch.float64)
+bacc_out = torch.zeros(ops.ACC_NREP, C, 4, device="cuda", dtype=torch.float64)
+mean_, rstd_ = torch.randn(C, device="cuda"), torch.rand(C, device="cuda") + 0.5
+dg_, db_, ds_ = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(1, device="cuda")
+print("backward stage, NB=3")
+print("   plain dgrad                          %.1f us" % timeit(lambda: ops.conv_fwd(x, wd, C, 3, 1)))
+print("   + fused input (y2, act, cA..) + dy   %.1f us" % timeit(lambda: ops.conv_dgrad_fused(x, y2, wd, C, 3, cA=cA, cB=cB, cC=cC, in_scale=sc, in_shift=sh, in_slope_const=0.2, in_act=1)))
+print("   + residual + epilogue partial tiles  %.1f us" % timeit(lambda: ops.conv_dgrad_fused(x, y2, wd, C, 3, cA=cA, cB=cB, cC=cC, in_scale=sc, in_shift=sh, in_slope_const=0.2, in_act=1, residual=res, epi_y=ys, epi_scale=sc, epi_shift=sh, epi_slope_const=0.2, epi_act=1)))
+print("   accumulator mode (in + out)          %.1f us" % timeit(lambda: ops.conv_dgrad_fused_acc(x, wd, C, 3, y2=y2, in_scale=sc, in_shift=sh, in_slope_const=0.2, in_act=1, residual=res, epi_y=ys, epi_scale=sc, epi_shift=sh, epi_slope_const=0.2, epi_act=1, bw_in_acc=bacc_in, bn=(mean_, rstd_, gam), n=n, dgamma=dg_, dbeta=db_, dslope=ds_, bw_st_acc=bacc_out)))
