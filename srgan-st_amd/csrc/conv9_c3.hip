@@ -367,11 +367,14 @@ SST_API int sst_conv9_c3_fwd(const float* x, const float* wp, float* y, const fl
 //   Step 1 (MFMA): T[y][x'][q] = sum_{ky,ci} P[y+ky-4][x'][ci] * W[co][ci][ky][kx],  q = 3*kx + co  (27 of 32 columns)
 //   Step 2 (LDS) : out[y][x][co] = bias[co] + sum_kx T[y][x+kx-4][3*kx+co]
 // Workgroup = 512 threads = 8 rows x 24 output pixels (32-pixel M fragment incl. the +-4 halo), one wave per row;
-// the 16-row x 32-pixel x 64-channel input patch is staged once in LDS (139 KB) and reused by all 9 ky.
+// the 16-row x 32-pixel input patch is staged 32 channels at a time in LDS (74 KB) and reused by all 9 ky.
 namespace {
 
-constexpr int T3_TH = 8, T3_TW = 24, T3_NT = 512;
+constexpr int T3_TH = 8, T3_TW = 24, T3_NT = 512;     // 8 waves, one output row each (4 waves x 2 rows measured slower: 103 vs 88 us)
 constexpr int T3_PW = 32, T3_PH = T3_TH + 8;
+// input channels staged per pass: 32 (two passes per 64-block) keeps the patch at 74 KB, so TWO workgroups fit a CU and one's
+// staging / fold overlaps the other's MFMAs (with 64 channels = 139 KB there is one workgroup per CU and nothing overlaps)
+constexpr int T3_CB = 32, T3_LDSC = T3_CB + 4;
 
 struct To3Args {
   const float* x;        // [B,H,W,C]
@@ -401,12 +404,14 @@ __global__ __launch_bounds__(T3_NT) void conv9_to3_fwd_kernel(To3Args a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int cb = 0; cb < ncb; ++cb) {
-    const int c0 = cb * CB;
-    const int nks = (min(CB, a.C - c0) + 7) >> 3;
+  for (int pass = 0; pass < 2 * ncb; ++pass) {
+    const int cb = pass >> 1, half = pass & 1;
+    const int c0 = cb * CB + half * T3_CB;
+    if (c0 >= a.C) break;
+    const int nks = (min(T3_CB, a.C - c0) + 7) >> 3;
     const int nchunks = 9 * nks;
-    const float* wblk = a.wp + (size_t)cb * 9 * 8 * 256 + lane * 4;
-    int p_ks = 0, p_off = 0, p_i = 0;
+    const float* wblk = a.wp + (size_t)cb * 9 * 8 * 256 + lane * 4;     // packed per 64-block: chunk (ky, ks) at (ky*8 + ks)*256
+    int p_ks = 0, p_off = half * 4 * 256, p_i = 0;
     auto pf_load = [&]() {
       const float* src = p_i < nchunks ? wblk + p_off : wzero;
       const f32x4 v = *reinterpret_cast<const f32x4*>(src);
@@ -417,10 +422,10 @@ __global__ __launch_bounds__(T3_NT) void conv9_to3_fwd_kernel(To3Args a) {
       return v;
     };
     f32x4 A0 = pf_load(), A1 = pf_load(), A2 = pf_load(), B0, B1, B2;
-    if (cb) __syncthreads();
+    if (pass) __syncthreads();
     {
-      const int c4 = (tid & 15) * 4, c = c0 + c4;
-      for (int p = tid >> 4; p < T3_PH * T3_PW; p += T3_NT / 16) {
+      const int c4 = (tid & 7) * 4, c = c0 + c4;
+      for (int p = tid >> 3; p < T3_PH * T3_PW; p += T3_NT / 8) {
         const int py = p / T3_PW, px = p - py * T3_PW;
         const int iy = y0 - 4 + py, ix = x0 - 4 + px;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -431,17 +436,17 @@ __global__ __launch_bounds__(T3_NT) void conv9_to3_fwd_kernel(To3Args a) {
             for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
           }
         }
-        *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = v;
+        *reinterpret_cast<f32x4*>(&lds[p * T3_LDSC + c4]) = v;
       }
     }
     __syncthreads();
     // A cursor: patch row (wave + ky), pixel li, channels ks*8 + 4*lh
-    int a_off = (wave * T3_PW + li) * LDSC + 4 * lh, a_ks = 0, a_i = 0;
+    int a_off = (wave * T3_PW + li) * T3_LDSC + 4 * lh, a_ks = 0, a_i = 0;
     auto a_load = [&]() {
       const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[a_off]);
       const bool live = a_i + 1 < nchunks;
       const bool wrap = (a_ks + 1 == nks);
-      a_off += live ? (wrap ? T3_PW * LDSC - 8 * (nks - 1) : 8) : 0;
+      a_off += live ? (wrap ? T3_PW * T3_LDSC - 8 * (nks - 1) : 8) : 0;
       a_ks = wrap ? 0 : a_ks + 1;
       ++a_i;
       return v;
@@ -520,7 +525,7 @@ SST_API int sst_conv9_to3_fwd(const float* x, const float* wp, float* y, float* 
   a.in_act = in_act; a.B = B; a.H = H; a.W = W; a.C = C;
   const int64_t mt = (int64_t)B * ((H + T3_TH - 1) / T3_TH) * ((W + T3_TW - 1) / T3_TW);
   SST_REQUIRE(mt < (1ll << 31), "sst_conv9_to3_fwd: too many tiles");
-  const size_t smem = (size_t)T3_PH * T3_PW * LDSC * sizeof(float);
+  const size_t smem = (size_t)T3_PH * T3_PW * T3_LDSC * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_to3_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
