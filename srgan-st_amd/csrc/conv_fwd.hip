@@ -41,7 +41,7 @@ inline bool use_big_tiles(const Conv3Args& a, int ksize) {
 }
 
 template <int KS, int S>
-__global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
+__device__ __forceinline__ void conv_fwd_body(const Conv3Args& a, const int bx, const int by) {
   const int KK = a.ksy * a.ksx;
   constexpr int PW = (TWO - 1) * S + KS, PH = (THO - 1) * S + KS, NP = PW * PH;
   constexpr int LDS_FLOATS = (NP * LDSC > 4 * 32 * 33) ? NP * LDSC : 4 * 32 * 33;
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
   const int tiles_x = (a.Wo + TWO - 1) / TWO, tiles_y = (a.Ho + THO - 1) / THO;
-  const int mt = blockIdx.x;
+  const int mt = bx;
   const int b = mt / (tiles_x * tiles_y), rt = mt - b * tiles_x * tiles_y;
   const int oy0 = (rt / tiles_x) * THO, ox0 = (rt % tiles_x) * TWO;
-  const int nf = blockIdx.y;
+  const int nf = by;
   const int iy0 = oy0 * S - a.pad_y, ix0 = ox0 * S - a.pad_x;
   const int ncb = (a.Cin + CB - 1) / CB;
   const int li = lane & 31, lh = lane >> 5;
@@ -214,6 +214,31 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
     return;
   }
   conv_tile_epilogue(a, lds, sstat, acc, b, oy0, ox0, nf, mt, true, tid, wave, lane);
+}
+
+template <int KS, int S>
+__global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
+  conv_fwd_body<KS, S>(a, blockIdx.x, blockIdx.y);
+}
+
+// Data-gradient of a stride-2 conv: the 4 parity classes of the input-gradient pixels (1 / 2 / 2 / 4 taps) in ONE launch
+// (blockIdx.z = class) instead of four short ones - the classes share nothing but run side by side and there is one launch
+// tail instead of four.
+struct S2Classes {
+  long long wp_off[4];
+  int nh[4], nw[4], tiles[4];
+};
+__global__ __launch_bounds__(CONV_NT) void conv_s2dgrad_kernel(Conv3Args a, S2Classes c) {
+  const int cls = blockIdx.z;
+  if ((int)blockIdx.x >= c.tiles[cls]) return;
+  a.wp += c.wp_off[cls];
+  a.ksy = 1 + (cls >> 1);
+  a.ksx = 1 + (cls & 1);
+  a.sub_y = cls >> 1;
+  a.sub_x = cls & 1;
+  a.Ho = c.nh[cls];
+  a.Wo = c.nw[cls];
+  conv_fwd_body<3, 1>(a, blockIdx.x, blockIdx.y);
 }
 
 // w [Cout][Cin][3][3] (reference layout) -> packed.  mode 0: forward.  mode 1: data-gradient of a stride-1
@@ -569,6 +594,38 @@ SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B
                               void* stream) {
   SST_REQUIRE(dy && wp && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "sst_conv_s2_dgrad: bad argument");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  {
+    // merged launch (all classes non-empty and none of them large enough for the 64x64-tile kernel)
+    Conv3Args a;
+    a.x = dy; a.wp = wp; a.y = dx; a.y_pre = nullptr; a.bias = nullptr;
+    a.in_scale = a.in_shift = a.in_slope = nullptr; a.in_slope_const = 0.f; a.in_act = ACT_NONE;
+    a.residual = nullptr; a.stats = nullptr; a.stats_cnt = nullptr; a.out_mode = OUT_STRIDE2; a.dbg = 0;
+    a.epi_y = a.epi_scale = a.epi_shift = a.epi_slope = nullptr; a.epi_slope_const = 0.f; a.epi_act = 0; a.epi_partial = nullptr;
+    a.in2 = a.in_cA = a.in_cB = a.in_cC = nullptr; a.side_out = nullptr;
+    a.B = B; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin;
+    a.ksy = a.ksx = 1; a.pad_y = a.pad_x = 0; a.sub_y = a.sub_x = 0; a.Ho = a.Wo = 0; a.Hy = H; a.Wy = W;
+    S2Classes c;
+    bool ok = !getenv("SST_S2_SPLIT");
+    int max_tiles = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int py = cls >> 1, px = cls & 1;
+      c.nh[cls] = (H - py + 1) / 2;
+      c.nw[cls] = (W - px + 1) / 2;
+      c.wp_off[cls] = s2_class_offset(cls, Cin, Cout);
+      c.tiles[cls] = (c.nh[cls] > 0 && c.nw[cls] > 0) ? sst_conv_mtiles(B, c.nh[cls], c.nw[cls]) : 0;
+      if (c.tiles[cls] == 0) ok = false;
+      Conv3Args t = a;
+      t.Ho = c.nh[cls]; t.Wo = c.nw[cls];
+      if (c.tiles[cls] && use_big_tiles(t, 3)) ok = false;
+      max_tiles = c.tiles[cls] > max_tiles ? c.tiles[cls] : max_tiles;
+    }
+    if (ok) {
+      dim3 grid((unsigned)max_tiles, (Cin + 31) / 32, 4);
+      conv_s2dgrad_kernel<<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, c);
+      SST_LAUNCH_CHECK("conv_s2dgrad_kernel");
+      return SST_OK;
+    }
+  }
   for (int cls = 0; cls < 4; ++cls) {
     const int py = cls >> 1, px = cls & 1;
     const int nh = (H - py + 1) / 2, nw = (W - px + 1) / 2;   // pixels of this parity class
