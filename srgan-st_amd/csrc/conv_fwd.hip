@@ -241,6 +241,54 @@ __global__ __launch_bounds__(CONV_NT) void conv_s2dgrad_kernel(Conv3Args a, S2Cl
   conv_fwd_body<3, 1>(a, blockIdx.x, blockIdx.y);
 }
 
+// 3x3 / stride 1 / pad 1 conv with a 3-CHANNEL input and bias (Discriminator.features[0], model.py:32: the image enters the
+// network).  K = 27: an MFMA tile would be 27/64 deep and the general kernel runs this shape at 7 TFLOP/s; the op is bound by
+// writing its 64-channel output (37.7 MB at 96 px, B = 16), so: plain VALU, one workgroup per output row, the 3 input rows in
+// LDS, a thread keeps the 27 x 4 weights of its 4 output channels in registers and walks the row's pixels.
+// Weights are read from the ordinary packed buffer (packed_index with i < 3).
+__global__ __launch_bounds__(CONV_NT) void conv3_c3in_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
+                                                             int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];            // [3][(W+2)*3 + 1]
+  const int RS = (W + 2) * 3 + 1;
+  const int b = blockIdx.x / H, oy = blockIdx.x - b * H;
+  for (int i = threadIdx.x; i < 3 * RS; i += CONV_NT) {
+    const int r = i / RS, o = i - r * RS;
+    const int px = o / 3 - 1, iy = oy - 1 + r;
+    float v = 0.f;
+    if (o < (W + 2) * 3 && (unsigned)px < (unsigned)W && (unsigned)iy < (unsigned)H)
+      v = x[(((size_t)b * H + iy) * W + px) * 3 + (o - (px + 1) * 3)];
+    xs[i] = v;
+  }
+  const int nq = Cout >> 2;                       // output-channel quads; CONV_NT % nq == 0 (host check)
+  const int cq = threadIdx.x % nq, pl = threadIdx.x / nq, npl = CONV_NT / nq;
+  const int co = cq * 4;
+  float w[27][4];                                 // [tap*3 + ci][j]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[t * 3 + ci][j] = wp[((((co + j) >> 5) * 9 + t) * 512 + ((co + j) & 31)) * 4 + ci];
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + co);
+  __syncthreads();
+  for (int ox = pl; ox < W; ox += npl) {
+    f32x4 acc = bv;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const float* row = xs + ky * RS + ox * 3;   // 9 contiguous floats: (kx, ci)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const float v = row[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, w[ky * 9 + q][j], acc[j]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + (((size_t)b * H + oy) * W + ox) * Cout + co) = acc;
+  }
+}
+
 // w [Cout][Cin][3][3] (reference layout) -> packed.  mode 0: forward.  mode 1: data-gradient of a stride-1
 // conv (outputs = Cin, inputs = Cout, taps rotated 180 degrees).  Stride-2 data-gradients use
 // pack_s2_dgrad_kernel below (one compact tap list per output-pixel parity class).
@@ -438,6 +486,15 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   hipStream_t st = sst_stream(stream);
   const size_t extra_lds = (size_t)(dbg_bits >> 4) * 1024;   // dev knob: pad LDS to cap workgroups per CU
   a.dbg = dbg_bits & 15;
+  if (ksize == 3 && stride == 1 && Cin == 3 && (Cout & 3) == 0 && CONV_NT % (Cout >> 2) == 0 && out_mode == OUT_NHWC && !in_scale &&
+      in_act == ACT_NONE && !residual && !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !getenv("SST_NO_C3IN")) {
+    const size_t lds = (size_t)3 * ((W + 2) * 3 + 1) * sizeof(float);
+    if (lds <= 48 * 1024) {
+      conv3_c3in_kernel<<<(unsigned)(B * H), CONV_NT, lds, st>>>(x, wp, bias, y, B, H, W, Cout);
+      SST_LAUNCH_CHECK("conv3_c3in_kernel");
+      return SST_OK;
+    }
+  }
   if (out_mode == OUT_NHWC && !(dbg_bits & 8)) {
     const int R = sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride);
     if (R) return sst_launch_conv_band(a, R, st, band_acc);
@@ -462,6 +519,8 @@ SST_API const char* sst_conv_kernel_name(int B, int H, int W, int Cin, int Cout,
   a.Ho = (H + 2 * p - ksize) / stride + 1;
   a.Wo = (W + 2 * p - ksize) / stride + 1;
   a.in2 = fused_in ? reinterpret_cast<const float*>(1) : nullptr;
+  if (ksize == 3 && stride == 1 && Cin == 3 && (Cout & 3) == 0 && CONV_NT % (Cout >> 2) == 0 && out_mode == OUT_NHWC && !fused_in)
+    return "conv3_c3in_kernel";      // (when called without input affine / activation / residual / statistics)
   if (out_mode == OUT_NHWC) {
     const int R = sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride);
     if (R) return R * W / 16 == 9 ? "conv_band_kernel<9>" : "conv_band_kernel<3>";

@@ -468,3 +468,23 @@ def test_conv_wgrad_three_channel_input(ops, case, monkeypatch):
     dw2 = torch.empty_like(dw)
     ops.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw2, 3, 1)
     assert rel_err(dw2.cpu(), w.grad) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 24, 20, 64), (1, 96, 96, 64), (3, 13, 9, 128), (2, 8, 8, 16)])
+def test_conv_fwd_three_channel_input(ops, case, monkeypatch):
+    """3x3 stride-1 conv from a 3-channel image with bias (Discriminator.features[0]): dedicated VALU kernel vs fp64 conv2d and
+    vs the general kernel."""
+    B, H, W, Cout = case
+    from srganst import _abi
+    g = torch.Generator().manual_seed(97)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(Cout, 3, 3, 3, generator=g) / 5.0
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    assert _abi.lib().sst_conv_kernel_name(B, H, W, 3, Cout, 3, 1, 0, 0) == b"conv3_c3in_kernel"
+    wp = ops.pack_conv(w.cuda())
+    y = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, 3, 1, bias=b.cuda())[0]
+    assert rel_err(nchw(y.cpu()), ref) < TOL
+    monkeypatch.setenv("SST_NO_C3IN", "1")
+    y2 = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, 3, 1, bias=b.cuda())[0]
+    assert rel_err(y2.cpu(), y.cpu()) < TOL
