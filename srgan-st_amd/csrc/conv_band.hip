@@ -19,6 +19,7 @@
 #include "conv_common.h"
 #include "conv_epilogue.h"
 #include <cstdlib>
+#include <type_traits>
 
 int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st, const BandAcc* acc);
 int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
@@ -322,11 +323,29 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     }
   }
 
-  auto reduce16 = [](float t) {   // over the 16 lanes that share lane/16 (same output channels)
-    t += __shfl_xor(t, 1, 64);
-    t += __shfl_xor(t, 2, 64);
-    t += __shfl_xor(t, 4, 64);
-    t += __shfl_xor(t, 8, 64);
+  // sum over the 16 lanes that share lane/16 (same output channels): DPP row rotations (VALU speed, no LDS crossbar);
+  // every lane of the row ends up with the row total
+  auto ror = [](float t, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  auto reduce16 = [&](float t) {
+    t += ror(t, std::integral_constant<int, 0x128>{});   // row_ror:8
+    t += ror(t, std::integral_constant<int, 0x124>{});   // row_ror:4
+    t += ror(t, std::integral_constant<int, 0x122>{});   // row_ror:2
+    t += ror(t, std::integral_constant<int, 0x121>{});   // row_ror:1
+    return t;
+  };
+  auto ror_d = [](double t, auto ctrl) {
+    const long long b = __builtin_bit_cast(long long, t);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), decltype(ctrl)::value, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  };
+  auto reduce16_d = [&](double t) {
+    t += ror_d(t, std::integral_constant<int, 0x128>{});
+    t += ror_d(t, std::integral_constant<int, 0x124>{});
+    t += ror_d(t, std::integral_constant<int, 0x122>{});
+    t += ror_d(t, std::integral_constant<int, 0x121>{});
     return t;
   };
 
@@ -345,10 +364,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       s1[j] = reduce16(s1[j]);
-      q[j] += __shfl_xor(q[j], 1, 64);
-      q[j] += __shfl_xor(q[j], 2, 64);
-      q[j] += __shfl_xor(q[j], 4, 64);
-      q[j] += __shfl_xor(q[j], 8, 64);
+      q[j] = reduce16_d(q[j]);
     }
     if (lp16 == 0) {
 #pragma unroll
