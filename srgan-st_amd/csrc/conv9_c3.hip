@@ -112,18 +112,22 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
         }
       }
     };
+    // two register sets in ping-pong (no register moves between iterations: the compiler then keeps counted LDS waits
+    // instead of draining lgkmcnt before every copy); the overshooting prefetch re-reads the last pair
+    float an[NU], bn[NU];
     load_pair(0, av, bv);
-    for (int kk = 0; kk < npair; ++kk) {
-      float an[NU], bn[NU];
-      load_pair(kk + 1 < npair ? kk + 1 : kk, an, bn);
+    for (int kk = 0; kk < npair; kk += 2) {
+      load_pair(kk + 1 < npair ? kk + 1 : npair - 1, an, bn);
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         if (u < NU - 1 || last_ok) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[u], 0, 0, 0);
       }
+      load_pair(kk + 2 < npair ? kk + 2 : npair - 1, av, bv);
+      if (kk + 1 < npair) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        av[u] = an[u];
-        bv[u] = bn[u];
+        for (int u = 0; u < NU; ++u) {
+          if (u < NU - 1 || last_ok) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[u], bn[u], acc[u], 0, 0, 0);
+        }
       }
     }
   }
