@@ -146,6 +146,14 @@ int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin);
 int sst_conv_s2_dgrad_pack(const float* w, float* wp, int Cout, int Cin, void* stream);
 int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout,
                       void* stream);
+/* one BatchNorm-backward stage around the stride-2 data-gradient (contract of sst_conv_dgrad_fused; g / y2 / dy_out live on the
+ * conv's output side [B,Ho,Wo,Cout], dx / epi_y are [B,H,W,Cin]); epi_partial [sst_conv_s2_dgrad_tiles(B,H,W)][3][Cin] */
+int sst_conv_s2_dgrad_tiles(int B, int H, int W);
+int sst_conv_s2_dgrad_fused(const float* g, const float* y2, const float* cA, const float* cB, const float* cC,
+                            const float* in_scale, const float* in_shift, const float* in_slope, float in_slope_const,
+                            int in_act, float* dy_out, const float* wp, float* dx, const float* epi_y,
+                            const float* epi_scale, const float* epi_shift, const float* epi_slope, float epi_slope_const,
+                            int epi_act, float* epi_partial, int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* weight gradients of njobs layers of IDENTICAL shape in ONE launch (the 33 trunk-shaped convs of the generator):
  * jobs = device array of {const float* x, *dy; float* slab, *dw; const float* in_scale, *in_shift, *in_slope;

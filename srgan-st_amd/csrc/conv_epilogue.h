@@ -199,13 +199,17 @@ __device__ __forceinline__ void conv_tile_epilogue(const Conv3Args& a, float* ld
   if (a.epi_partial) {
     // backward partials for the BatchNorm / activation that produced this conv's consumer-side input (see Conv3Args)
     const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
+    // epi_y is addressed like the STORED tensor: for the parity-class store that is the full-resolution pixel
+    const size_t ebase = a.out_mode == OUT_STRIDE2
+                             ? (((size_t)b * a.Hy + 2 * oy + a.sub_y) * a.Wy + 2 * ox + a.sub_x) * a.Cout + n0
+                             : obase;
     float q[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float g = 0.f, yv = 0.f, z = 0.f;
       if (pix_ok && n0 + j < a.Cout) {
         g = v[j];
-        yv = a.epi_y[obase + j];
+        yv = a.epi_y[ebase + j];
         z = a.epi_scale ? fmaf(yv, a.epi_scale[n0 + j], a.epi_shift[n0 + j]) : yv;
       }
       float gz = g;

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
 struct S2Classes {
   long long wp_off[4];
   int nh[4], nw[4], tiles[4];
+  int tile_base[4];          // first partial tile of the class (epi_partial is [sum of tiles][3][Cout])
 };
 __global__ __launch_bounds__(CONV_NT) void conv_s2dgrad_kernel(Conv3Args a, S2Classes c) {
   const int cls = blockIdx.z;
@@ -238,6 +239,8 @@ __global__ __launch_bounds__(CONV_NT) void conv_s2dgrad_kernel(Conv3Args a, S2Cl
   a.sub_x = cls & 1;
   a.Ho = c.nh[cls];
   a.Wo = c.nw[cls];
+  if (cls) a.side_out = nullptr;                 // every class stages all dY pixels: class 0 writes the side output
+  if (a.epi_partial) a.epi_partial += (size_t)c.tile_base[cls] * 3 * a.Cout;
   conv_fwd_body<3, 1>(a, blockIdx.x, blockIdx.y);
 }
 
@@ -648,9 +651,24 @@ SST_API int sst_conv_s2_dgrad_pack(const float* w, float* wp, int Cout, int Cin,
   return SST_OK;
 }
 
-// dx [B,H,W,Cin] = conv_transpose(dy [B,Ho,Wo,Cout]) for y = conv3x3(x, stride 2, pad 1); 4 launches (parity classes).
-SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout,
-                              void* stream) {
+// dx [B,H,W,Cin] = conv_transpose(dy [B,Ho,Wo,Cout]) for y = conv3x3(x, stride 2, pad 1): the 4 parity classes of dx in one
+// launch (four when a class is empty or large enough for the 64x64-tile kernel).
+struct S2Fused {             // optional fused BatchNorm-backward stage around the data-gradient (see sst_conv_dgrad_fused)
+  const float* in2; const float* cA; const float* cB; const float* cC; const float* in_scale; const float* in_shift;
+  const float* in_slope; float in_slope_const; int in_act; float* dy_out;
+  const float* epi_y; const float* epi_scale; const float* epi_shift; const float* epi_slope; float epi_slope_const; int epi_act;
+  float* epi_partial;
+};
+SST_API int sst_conv_s2_dgrad_tiles(int B, int H, int W) {
+  int t = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int nh = (H - (cls >> 1) + 1) / 2, nw = (W - (cls & 1) + 1) / 2;
+    if (nh > 0 && nw > 0) t += sst_conv_mtiles(B, nh, nw);
+  }
+  return t;
+}
+static int conv_s2_dgrad_impl(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout, void* stream,
+                              const S2Fused* f) {
   SST_REQUIRE(dy && wp && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "sst_conv_s2_dgrad: bad argument");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   {
@@ -661,21 +679,30 @@ SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B
     a.residual = nullptr; a.stats = nullptr; a.stats_cnt = nullptr; a.out_mode = OUT_STRIDE2; a.dbg = 0;
     a.epi_y = a.epi_scale = a.epi_shift = a.epi_slope = nullptr; a.epi_slope_const = 0.f; a.epi_act = 0; a.epi_partial = nullptr;
     a.in2 = a.in_cA = a.in_cB = a.in_cC = nullptr; a.side_out = nullptr;
+    if (f) {
+      a.in2 = f->in2; a.in_cA = f->cA; a.in_cB = f->cB; a.in_cC = f->cC; a.side_out = f->dy_out;
+      a.in_scale = f->in_scale; a.in_shift = f->in_shift; a.in_slope = f->in_slope; a.in_slope_const = f->in_slope_const;
+      a.in_act = f->in_act;
+      a.epi_y = f->epi_y; a.epi_scale = f->epi_scale; a.epi_shift = f->epi_shift; a.epi_slope = f->epi_slope;
+      a.epi_slope_const = f->epi_slope_const; a.epi_act = f->epi_act; a.epi_partial = f->epi_partial;
+    }
     a.B = B; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin;
     a.ksy = a.ksx = 1; a.pad_y = a.pad_x = 0; a.sub_y = a.sub_x = 0; a.Ho = a.Wo = 0; a.Hy = H; a.Wy = W;
     S2Classes c;
-    bool ok = !getenv("SST_S2_SPLIT");
-    int max_tiles = 0;
+    bool ok = !getenv("SST_S2_SPLIT") || f;
+    int max_tiles = 0, tbase = 0;
     for (int cls = 0; cls < 4; ++cls) {
       const int py = cls >> 1, px = cls & 1;
       c.nh[cls] = (H - py + 1) / 2;
       c.nw[cls] = (W - px + 1) / 2;
       c.wp_off[cls] = s2_class_offset(cls, Cin, Cout);
       c.tiles[cls] = (c.nh[cls] > 0 && c.nw[cls] > 0) ? sst_conv_mtiles(B, c.nh[cls], c.nw[cls]) : 0;
-      if (c.tiles[cls] == 0) ok = false;
+      c.tile_base[cls] = tbase;
+      tbase += c.tiles[cls];
+      if (c.tiles[cls] == 0 && !f) ok = false;
       Conv3Args t = a;
       t.Ho = c.nh[cls]; t.Wo = c.nw[cls];
-      if (c.tiles[cls] && use_big_tiles(t, 3)) ok = false;
+      if (!f && c.tiles[cls] && use_big_tiles(t, 3)) ok = false;
       max_tiles = c.tiles[cls] > max_tiles ? c.tiles[cls] : max_tiles;
     }
     if (ok) {
@@ -684,6 +711,7 @@ SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B
       SST_LAUNCH_CHECK("conv_s2dgrad_kernel");
       return SST_OK;
     }
+    SST_REQUIRE(!f, "sst_conv_s2_dgrad_fused: merged launch not possible");
   }
   for (int cls = 0; cls < 4; ++cls) {
     const int py = cls >> 1, px = cls & 1;
@@ -708,4 +736,24 @@ SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B
     SST_LAUNCH_CHECK("conv_fwd_kernel<3,1> (s2 dgrad)");
   }
   return SST_OK;
+}
+
+SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout,
+                              void* stream) {
+  return conv_s2_dgrad_impl(dy, wp, dx, B, H, W, Cin, Cout, stream, nullptr);
+}
+
+// One BatchNorm-backward stage around a STRIDE-2 data-gradient (same contract as sst_conv_dgrad_fused; g / y2 / dy_out are
+// [B,Ho,Wo,Cout] of the conv's output side, dx / epi_y [B,H,W,Cin]); epi_partial: [sst_conv_s2_dgrad_tiles(B,H,W)][3][Cin].
+SST_API int sst_conv_s2_dgrad_fused(const float* g, const float* y2, const float* cA, const float* cB, const float* cC,
+                                    const float* in_scale, const float* in_shift, const float* in_slope, float in_slope_const,
+                                    int in_act, float* dy_out, const float* wp, float* dx, const float* epi_y,
+                                    const float* epi_scale, const float* epi_shift, const float* epi_slope, float epi_slope_const,
+                                    int epi_act, float* epi_partial, int B, int H, int W, int Cin, int Cout, void* stream) {
+  SST_REQUIRE(g && y2 && dy_out && (Cout & 3) == 0, "sst_conv_s2_dgrad_fused: g / y2 / dy_out, Cout %% 4 == 0");
+  SST_REQUIRE((epi_partial == nullptr) == (epi_y == nullptr), "sst_conv_s2_dgrad_fused: epi_y and epi_partial come together");
+  SST_REQUIRE(!cA || (cB && cC), "sst_conv_s2_dgrad_fused: cA / cB / cC come together");
+  const S2Fused f{y2, cA, cB, cC, in_scale, in_shift, in_slope, in_slope_const, in_act, dy_out,
+                  epi_y, epi_scale, epi_shift, epi_slope, epi_slope_const, epi_act, epi_partial};
+  return conv_s2_dgrad_impl(g, wp, dx, B, H, W, Cin, Cout, stream, &f);
 }

@@ -406,6 +406,26 @@ def conv_s2_dgrad(dy, wp, H, W, cin):
     return dx
 
 
+def conv_s2_dgrad_fused(g, y2, wp, H, W, cin, cA=None, cB=None, cC=None, in_scale=None, in_shift=None, in_slope=None,
+                        in_slope_const=0.0, in_act=0, epi_y=None, epi_scale=None, epi_shift=None, epi_slope=None, epi_slope_const=0.0,
+                        epi_act=0):
+    """conv_dgrad_fused for a stride-2 conv: g / y2 [B,Ho,Wo,Cout] (conv output side), returns (dx [B,H,W,cin], dy, partial | None)."""
+    B, ho, wo, cout = g.shape
+    dx = _f32(B, H, W, cin, like=g)
+    dy = torch.empty_like(g)
+    partial = _f32(_abi.lib().sst_conv_s2_dgrad_tiles(B, H, W), 3, cin, like=g) if epi_y is not None else None
+    args = (ptr(g), ptr(y2), ptr(cA), ptr(cB), ptr(cC), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const), int(in_act),
+            ptr(dy), ptr(wp), ptr(dx), ptr(epi_y), ptr(epi_scale), ptr(epi_shift), ptr(epi_slope), float(epi_slope_const), int(epi_act),
+            ptr(partial), B, H, W, cin, cout)
+    e0 = _prof_begin()
+    check(_abi.lib().sst_conv_s2_dgrad_fused(*args, stream_ptr()), "sst_conv_s2_dgrad_fused")
+    flops = 2.0 * B * ho * wo * cout * cin * 9
+    _prof_end(e0, "conv_s2dgrad_kernel", flops)
+    _trace("conv_s2dgrad_kernel", flops, lambda: _abi.lib().sst_conv_s2_dgrad_fused(*args, stream_ptr()),
+           g, y2, cA, cB, cC, in_scale, in_shift, in_slope, dy, wp, dx, epi_y, epi_scale, epi_shift, epi_slope, partial)
+    return dx, dy, partial
+
+
 def linear_fwd(x, w, bias):
     M, K = x.shape
     N = w.shape[0]

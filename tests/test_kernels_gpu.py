@@ -488,3 +488,36 @@ def test_conv_fwd_three_channel_input(ops, case, monkeypatch):
     monkeypatch.setenv("SST_NO_C3IN", "1")
     y2 = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, 3, 1, bias=b.cuda())[0]
     assert rel_err(y2.cpu(), y.cpu()) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 12, 12, 128, 64), (2, 9, 13, 64, 128), (1, 6, 6, 256, 256)])
+def test_conv_s2_dgrad_fused_stage(ops, case):
+    """BatchNorm-backward stage around the stride-2 data-gradient (apply on load, dy side output, partial sums of the result
+    against the previous layer's output) vs explicit composition in fp64."""
+    B, H, W, Cin, Cout = case
+    g_ = torch.Generator().manual_seed(99)
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w = torch.randn(Cout, Cin, 3, 3, generator=g_) / (Cin * 9) ** 0.5
+    gup = torch.randn(B, Cout, ho, wo, generator=g_)              # gradient w.r.t. LeakyReLU(BN(y2))
+    y2 = torch.randn(B, Cout, ho, wo, generator=g_)
+    sc, sh = torch.rand(Cout, generator=g_) + 0.5, torch.randn(Cout, generator=g_) * 0.3
+    cA, cB, cC = (torch.randn(Cout, generator=g_) for _ in range(3))
+    v = lambda t: t.double().view(1, -1, 1, 1)
+    z = y2.double() * v(sc) + v(sh)
+    gz = torch.where(z > 0, gup.double(), gup.double() * 0.2)
+    dy_ref = v(cA) * gz + v(cB) * y2.double() + v(cC)
+    dx_ref = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy_ref, 2, 1)
+    yprev = torch.randn(B, Cin, H, W, generator=g_)
+    esc, esh = torch.rand(Cin, generator=g_) + 0.5, torch.randn(Cin, generator=g_) * 0.3
+    dx, dy, part = ops.conv_s2_dgrad_fused(nhwc(gup).cuda(), nhwc(y2).cuda(), ops.pack_conv_s2_dgrad(w.cuda()), H, W, Cin,
+                                           cA=cA.cuda(), cB=cB.cuda(), cC=cC.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(),
+                                           in_slope_const=0.2, in_act=1, epi_y=nhwc(yprev).cuda(), epi_scale=esc.cuda(),
+                                           epi_shift=esh.cuda(), epi_slope_const=0.2, epi_act=1)
+    assert rel_err(nchw(dy.cpu()), dy_ref) < TOL
+    assert rel_err(nchw(dx.cpu()), dx_ref) < TOL
+    zp = yprev.double() * esc.double().view(1, -1, 1, 1) + esh.double().view(1, -1, 1, 1)
+    gzp = torch.where(zp > 0, dx_ref, dx_ref * 0.2)
+    tot = part.sum(dim=0).cpu()
+    assert rel_err(tot[0], gzp.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(tot[1], (gzp * yprev.double()).sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_err(tot[2], (dx_ref * zp.clamp(max=0)).sum(dim=(0, 2, 3))) < 1e-4
