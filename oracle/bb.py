@@ -1,0 +1,46 @@
+"""CPU restatement of the reference's BestBuddyLoss (loss.py:78-142, utils.py:157-191) - TEST INFRASTRUCTURE ONLY.
+
+Best-buddy matching: the SR image and the GT image are cut into non-overlapping k x k patches (unfold, channel-major
+C*k*k vectors); the candidate set is the GT patches at full, 1/2 and 1/4 resolution (torch bicubic, align_corners=False,
+no antialiasing); every SR patch i is paired with the candidate j minimising
+    alpha * ||p_sr[i] - c[j]||^2 + beta * ||p_gt[i] - c[j]||^2      (squared L2 via  |x|^2 + |y|^2 - 2 x.y, clamped at 0)
+and the loss is the L1 (or L2) criterion between the SR patches and their buddies.  Only the final criterion is
+differentiated (argmin indices carry no gradient)."""
+import torch
+import torch.nn.functional as F
+
+
+def pairwise_sq_l2(x, y):
+    """utils.py:173-187: dist[b,i,j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j, clamped to [0, inf)."""
+    xn = (x ** 2).sum(dim=2).unsqueeze(2)
+    yn = (y ** 2).sum(dim=2).unsqueeze(1)
+    return torch.clamp(xn + yn - 2.0 * torch.bmm(x, y.transpose(1, 2)), 0.0)
+
+
+def pairwise_l1(x, y):
+    return (x.unsqueeze(2) - y.unsqueeze(1)).abs().sum(dim=3)
+
+
+def patches(img, ksize=3, pad=0, stride=3):
+    """loss.py:116-118: F.unfold -> [B, n_patches, C*k*k]."""
+    return F.unfold(img, kernel_size=ksize, padding=pad, stride=stride).permute(0, 2, 1).contiguous()
+
+
+def candidates(gt, ksize=3, pad=0, stride=3):
+    """loss.py:119-129: GT patches at scales 1, 1/2, 1/4 concatenated."""
+    gt2 = F.interpolate(gt, scale_factor=0.5, mode="bicubic", align_corners=False)
+    gt4 = F.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False)
+    return torch.cat([patches(gt, ksize, pad, stride), patches(gt2, ksize, pad, stride), patches(gt4, ksize, pad, stride)], 1), gt2, gt4
+
+
+def best_buddy_loss(x, gt, alpha=1.0, beta=1.0, ksize=3, pad=0, stride=3, dist_norm="l2", criterion="l1"):
+    """-> (loss, ind [B, n_patches], score [B, n_patches, n_candidates])."""
+    p1 = patches(x, ksize, pad, stride)
+    p2 = patches(gt, ksize, pad, stride)
+    cat, _, _ = candidates(gt, ksize, pad, stride)
+    dist = pairwise_sq_l2 if dist_norm == "l2" else pairwise_l1
+    score = alpha * dist(p1, cat) + beta * dist(p2, cat)
+    ind = torch.min(score, dim=2)[1]
+    sel = torch.gather(cat, 1, ind.unsqueeze(-1).expand(-1, -1, p1.shape[2]))
+    loss = F.l1_loss(p1, sel) if criterion == "l1" else F.mse_loss(p1, sel)
+    return loss, ind, score

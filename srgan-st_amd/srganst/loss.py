@@ -176,6 +176,93 @@ def criterion_sum(sr, gt, terms, weights, ws=None):
     return _CriterionSumFn.apply(sr, gt, list(terms), list(weights), ws)
 
 
+# ------------------------------------------------------------------------------------------------
+def _torch_bicubic_taps(in_size: int, out_size: int, device):
+    """Tap tables of F.interpolate(mode='bicubic', align_corners=False) (A = -0.75, 4 taps, border indices clamped):
+    -> (weights [out, 4] fp32, indices [out, 4] int32)."""
+    A = -0.75
+    o = torch.arange(out_size, dtype=torch.float64)
+    src = (o + 0.5) * (in_size / out_size) - 0.5
+    x0 = torch.floor(src)
+    t = src - x0
+
+    def cc1(x):
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+
+    def cc2(x):
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+
+    w = torch.stack([cc2(t + 1), cc1(t), cc1(1 - t), cc2(2 - t)], dim=1).to(torch.float32)
+    idx = (x0.unsqueeze(1) + torch.arange(-1, 3, dtype=torch.float64).unsqueeze(0)).clamp(0, in_size - 1).to(torch.int32)
+    return w.contiguous().to(device), idx.contiguous().to(device)
+
+
+class _BestBuddyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gt, alpha, beta, l2, cache):
+        if x.dtype != torch.float32 or x.shape != gt.shape or x.dim() != 4 or x.shape[1] != 3:
+            raise _abi.HipPathError("BestBuddyLoss: fp32 [B,3,H,W] pairs")
+        B, _, H, W = x.shape
+        if H % 12 or W % 12:
+            raise _abi.HipPathError("BestBuddyLoss: H and W must be multiples of 12 (3x3 patches at scales 1, 1/2, 1/4)")
+        x, gt = x.contiguous(), gt.contiguous()
+        lib, dev = _abi.lib(), x.device
+        key = (dev, H, W)
+        if cache.get("key") != key:
+            cache["key"] = key
+            cache["taps"] = [(_torch_bicubic_taps(H, H // s, dev), _torch_bicubic_taps(W, W // s, dev)) for s in (2, 4)]
+        nps = [(H // s // 3) * (W // s // 3) for s in (1, 2, 4)]
+        ncand = sum(nps)
+        cand = torch.empty(B, ncand, 27, device=dev, dtype=torch.float32)
+        cnrm = torch.empty(B, ncand, device=dev, dtype=torch.float32)
+        st = _abi.stream_ptr()
+        _abi.check(lib.sst_bb_patches(_abi.ptr(gt), _abi.ptr(cand), _abi.ptr(cnrm), B, H, W, ncand, 0, st), "sst_bb_patches")
+        off = nps[0]
+        for k, s in enumerate((2, 4)):                       # GT at 1/2 and 1/4 resolution (torch bicubic), then its patches
+            (wy, iy), (wx, ix) = cache["taps"][k]
+            small = torch.empty(B, 3, H // s, W // s, device=dev, dtype=torch.float32)
+            _abi.check(lib.sst_bicubic(_abi.ptr(gt), _abi.ptr(small), _abi.ptr(wy), _abi.ptr(iy), _abi.ptr(wx), _abi.ptr(ix), B * 3, H, W,
+                                       H // s, W // s, 4, 4, 0, st), "sst_bicubic")
+            _abi.check(lib.sst_bb_patches(_abi.ptr(small), _abi.ptr(cand), _abi.ptr(cnrm), B, H // s, W // s, ncand, off, st),
+                       "sst_bb_patches")
+            off += nps[k + 1]
+        ind = torch.empty(B, nps[0], device=dev, dtype=torch.int32)
+        dsr = torch.empty_like(x)
+        partials = torch.empty(lib.sst_bb_blocks(B, H, W), device=dev, dtype=torch.float32)
+        _abi.check(lib.sst_bb_match(_abi.ptr(x), _abi.ptr(cand), _abi.ptr(cnrm), _abi.ptr(ind), _abi.ptr(dsr), _abi.ptr(partials), B, H, W,
+                                    ncand, float(alpha), float(beta), int(l2), st), "sst_bb_match")
+        ctx.save_for_backward(dsr)
+        ctx.mark_non_differentiable(ind)
+        return partials.sum(), ind
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_ind):
+        (dsr,) = ctx.saved_tensors
+        return dsr * grad_out, None, None, None, None, None
+
+
+class BestBuddyLoss(nn.Module):
+    """Reference loss.py:78-142 (Best-Buddy GAN loss) on the HIP path.  Same constructor; supported configuration is the
+    reference's default geometry (ksize 3, pad 0, stride 3, dist_norm 'l2') with criterion 'l1' or 'l2' / 'mse'."""
+
+    def __init__(self, alpha: float = 1.0, beta: float = 1.0, ksize: int = 3, pad: int = 0, stride: int = 3, dist_norm: str = "l2",
+                 criterion: str = "l1") -> None:
+        super().__init__()
+        if (ksize, pad, stride, dist_norm) != (3, 0, 3, "l2"):
+            raise NotImplementedError("BestBuddyLoss on the HIP path: ksize=3, pad=0, stride=3, dist_norm='l2' only")
+        if criterion not in ("l1", "l2", "mse"):
+            raise NotImplementedError("%s criterion has not been implmented." % criterion)
+        self.alpha, self.beta, self.ksize, self.pad, self.stride, self.dist_norm = alpha, beta, ksize, pad, stride, dist_norm
+        self.l2 = criterion != "l1"
+        self._cache = {}
+        self.last_index = None          # [B, n_patches] int32: the selected candidate per SR patch (diagnostics / tests)
+
+    def forward(self, x, gt):
+        loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache)
+        self.last_index = ind
+        return loss
+
+
 class _BceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target_value):

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Golden fixture for BestBuddyLoss FROM THE REFERENCE (loss.py:78-142): inputs, loss, d(loss)/d(sr), the selected candidate
+per patch and the margin to the runner-up (so that tests can tell genuine mismatches from fp32 near-ties).
+Build container only (needs /root/reference).  Re-run:  python tests/golden/make_golden_bb.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_golden import import_reference, lowfreq, save  # noqa: E402
+
+
+def main():
+    _, _, _, rutils, rloss = import_reference()
+    gen = torch.Generator().manual_seed(4321)
+    arrs = {}
+    for name, (B, H) in {"lf48": (2, 48), "lf96": (1, 96)}.items():
+        gt = lowfreq(gen, B, H)
+        x = (gt + 0.08 * torch.randn(gt.shape, generator=gen)).clamp(0, 1).requires_grad_(True)
+        for crit in ("l1", "l2"):
+            mod = rloss.BestBuddyLoss(criterion=crit)
+            loss = mod(x, gt)
+            (gx,) = torch.autograd.grad(loss, x)
+            arrs[f"{name}/{crit}/loss"] = loss.detach().numpy()
+            arrs[f"{name}/{crit}/grad"] = gx.numpy()
+        # matching details from the reference's own helper (same calls as loss.py:116-134)
+        import torch.nn.functional as F
+        with torch.no_grad():
+            unf = lambda t: F.unfold(t, kernel_size=3, padding=0, stride=3).permute(0, 2, 1).contiguous()
+            p1, p2 = unf(x), unf(gt)
+            gt2 = F.interpolate(gt, scale_factor=0.5, mode="bicubic", align_corners=False)
+            gt4 = F.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False)
+            cat = torch.cat([p2, unf(gt2), unf(gt4)], 1)
+            score = rutils.batch_pairwise_distance(p1, cat, "l2") + rutils.batch_pairwise_distance(p2, cat, "l2")
+            top2 = torch.topk(score, 2, dim=2, largest=False)
+        arrs[f"{name}/x"], arrs[f"{name}/gt"] = x.detach().numpy(), gt.numpy()
+        arrs[f"{name}/gt2"], arrs[f"{name}/gt4"] = gt2.numpy(), gt4.numpy()
+        arrs[f"{name}/ind"] = top2.indices[..., 0].numpy().astype(np.int32)
+        arrs[f"{name}/margin"] = (top2.values[..., 1] - top2.values[..., 0]).numpy()
+    save("bestbuddy", **arrs)
+
+
+if __name__ == "__main__":
+    main()
