@@ -44,3 +44,27 @@ def best_buddy_loss(x, gt, alpha=1.0, beta=1.0, ksize=3, pad=0, stride=3, dist_n
     sel = torch.gather(cat, 1, ind.unsqueeze(-1).expand(-1, -1, p1.shape[2]))
     loss = F.l1_loss(p1, sel) if criterion == "l1" else F.mse_loss(p1, sel)
     return loss, ind, score
+
+
+# ---- GramLoss (reference loss.py:145-228): the same matching on the 3x3 gram matrix of every 3x3 patch
+def gram_patches(img, ksize=3):
+    """loss.py:182-201: non-overlapping k x k patches of a [B,3,H,W] image -> F = patch as [3, k*k]; G = F F^T / (3*k*k)
+    flattened row-major -> [B, n_patches, 9] (k = 3)."""
+    B = img.shape[0]
+    p = F.unfold(img, kernel_size=ksize, stride=ksize).permute(0, 2, 1)          # [B, nP, 3*k*k] in (c, ky, kx) order
+    Fm = p.reshape(B, -1, 3, ksize * ksize)
+    G = torch.matmul(Fm, Fm.transpose(2, 3)) / float(3 * ksize * ksize)
+    return G.reshape(B, -1, 9)
+
+
+def gram_loss(x, gt, alpha=1.0, beta=1.0, ksize=3, dist_norm="l2", criterion="l1"):
+    p1, p2 = gram_patches(x, ksize), gram_patches(gt, ksize)
+    gt2 = F.interpolate(gt, scale_factor=0.5, mode="bicubic", align_corners=False)
+    gt4 = F.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False)
+    cat = torch.cat([p2, gram_patches(gt2, ksize), gram_patches(gt4, ksize)], 1)
+    dist = pairwise_sq_l2 if dist_norm == "l2" else pairwise_l1
+    score = alpha * dist(p1, cat) + beta * dist(p2, cat)
+    ind = torch.min(score, dim=2)[1]
+    sel = torch.gather(cat, 1, ind.unsqueeze(-1).expand(-1, -1, p1.shape[2]))
+    loss = F.l1_loss(p1, sel) if criterion == "l1" else F.mse_loss(p1, sel)
+    return loss, ind, score

@@ -1,52 +1,76 @@
-// Best-buddy loss (reference loss.py:78-142 BestBuddyLoss, utils.py:157-191 batch_pairwise_distance) on the GPU.
+// Best-buddy losses on the GPU: reference loss.py:78-142 BestBuddyLoss and loss.py:145-228 GramLoss (matching via
+// utils.py:157-191 batch_pairwise_distance).
 //
-// The SR and GT images are cut into non-overlapping k x k patches (k = 3: 27-vectors in unfold order c*9 + ky*3 + kx); the
-// candidate set is the GT patches at scales 1, 1/2, 1/4; SR patch i is paired with the candidate j that minimises
-//   alpha * max(|p_sr_i|^2 + |c_j|^2 - 2 p_sr_i.c_j, 0) + beta * max(|p_gt_i|^2 + |c_j|^2 - 2 p_gt_i.c_j, 0)
-// (the reference's expanded squared distance, clamped) and the loss is the mean L1 (or L2) between the SR patches and their
-// buddies.  Only that last criterion is differentiated.
-//   bb_patches_kernel : image [B,3,H,W] -> patches [B, nP, 27] + squared norms, written into the candidate table
-//   bb_match_kernel   : 8 threads per SR patch scan interleaved slices of the candidates (LDS chunks, broadcast reads), the
-//                       argmin is combined, then the criterion term and the (unscaled) gradient of the patch's 27 pixels;
-//                       per-workgroup loss partials
+// The SR and GT images are cut into non-overlapping 3 x 3 patches (27-vectors F in unfold order c*9 + ky*3 + kx).  A patch's
+// FEATURE is the vector itself (BestBuddyLoss) or its 3x3 gram matrix G = F F^T / 27 with F viewed as [3 channels][9]
+// (GramLoss, 9-vector).  The candidate set is the GT features at scales 1, 1/2, 1/4; SR patch i is paired with the candidate j
+// minimising   alpha * max(|f_sr_i|^2 + |c_j|^2 - 2 f_sr_i.c_j, 0) + beta * max(|f_gt_i|^2 + |c_j|^2 - 2 f_gt_i.c_j, 0)
+// (the reference's expanded squared distance, clamped; first minimum wins like torch.min) and the loss is the mean L1 (or L2)
+// between the SR features and their buddies.  Only that last criterion is differentiated (through the gram map for GramLoss).
+//   bb_patches_kernel<GRAM> : image [B,3,H,W] -> features [B, nP, D] + squared norms, written into the candidate table
+//   bb_match_kernel<D,GRAM> : 32 query patches x 8 candidate splits per workgroup (all lanes of a wave read the SAME candidate
+//                             row from LDS: broadcast), argmin combined, then criterion term + gradient of the patch's 27
+//                             pixels; per-workgroup loss partials
 #include "common.h"
 
 namespace {
 
-constexpr int BB_D = 27;          // 3 channels x 3 x 3
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int BB_P = 27;                                       // raw patch: 3 channels x 3 x 3
 constexpr int BB_Q = 32, BB_SPLIT = 8, BB_NT = BB_Q * BB_SPLIT;   // query patches x candidate splits per workgroup
-constexpr int BB_CH = 128;        // candidates per LDS chunk
+constexpr int BB_CH = 128;                                     // candidates per LDS chunk
 
+template <int GRAM>
+__device__ __forceinline__ void bb_features(const float (&p)[BB_P], float* f) {   // f: 27 (raw) or 9 (gram) values
+  if (GRAM) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s = fmaf(p[a * 9 + k], p[b * 9 + k], s);
+        f[a * 3 + b] = s / 27.f;
+      }
+  } else {
+#pragma unroll
+    for (int d = 0; d < BB_P; ++d) f[d] = p[d];
+  }
+}
+
+template <int GRAM>
 __global__ __launch_bounds__(256) void bb_patches_kernel(const float* __restrict__ img, float* __restrict__ out, float* __restrict__ nrm,
                                                          int B, int H, int W, int ncand_total, int cand_off) {
+  constexpr int D = GRAM ? 9 : BB_P;
   const int ph = H / 3, pw = W / 3, np = ph * pw;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < B * np; i += gridDim.x * 256) {
     const int b = i / np, pidx = i - b * np, py = pidx / pw, px = pidx - py * pw;
-    float* o = out + ((size_t)b * ncand_total + cand_off + pidx) * BB_D;
-    float s = 0.f;
+    float p[BB_P], f[D];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float v = img[(((size_t)b * 3 + c) * H + py * 3 + ky) * W + px * 3 + kx];
-          o[c * 9 + ky * 3 + kx] = v;
-          s = fmaf(v, v, s);
-        }
+        for (int kx = 0; kx < 3; ++kx) p[c * 9 + ky * 3 + kx] = img[(((size_t)b * 3 + c) * H + py * 3 + ky) * W + px * 3 + kx];
+    bb_features<GRAM>(p, f);
+    float* o = out + ((size_t)b * ncand_total + cand_off + pidx) * D;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      o[d] = f[d];
+      s = fmaf(f[d], f[d], s);
+    }
     nrm[(size_t)b * ncand_total + cand_off + pidx] = s;
   }
 }
 
-// 32 query patches x 8 candidate splits per workgroup: lane = query, the 8 waves... (4 waves x 2) scan interleaved slices of
-// the candidate chunk (all lanes of a wave read the SAME candidate row: LDS broadcast, 7 x 16 B per row); the 8 partial
-// argmins of a query are combined with "lower score, then lower index" = torch.min's first minimum.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int GRAM>
 __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict__ sr, const float* __restrict__ cand,
                                                          const float* __restrict__ cnrm, int* __restrict__ ind_out,
                                                          float* __restrict__ dsr, float* __restrict__ partials, int B, int H, int W,
                                                          int ncand, float alpha, float beta, int l2, float inv_n) {
-  __shared__ __attribute__((aligned(16))) float sc[BB_CH][BB_D + 1];
+  constexpr int D = GRAM ? 9 : BB_P, DP = (D + 3) / 4 * 4;     // feature length, padded to 16-B rows in LDS
+  __shared__ __attribute__((aligned(16))) float sc[BB_CH][DP];
   __shared__ float sn[BB_CH];
   __shared__ float sbest[BB_SPLIT][BB_Q];
   __shared__ int sbi[BB_SPLIT][BB_Q];
@@ -58,28 +82,31 @@ __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict
   const int q = (blockIdx.x - b * nblk_img) * BB_Q + ql;
   const bool live = q < np;
   const int py = live ? q / pw : 0, px = live ? q - py * pw : 0;
-  float p1[BB_D + 1], p2[BB_D + 1];
-  float n1 = 0.f, n2 = 0.f;
+  float p[BB_P];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int d = c * 9 + ky * 3 + kx;
-        p1[d] = live ? sr[(((size_t)b * 3 + c) * H + py * 3 + ky) * W + px * 3 + kx] : 0.f;
-        p2[d] = live ? cand[((size_t)b * ncand + q) * BB_D + d] : 0.f;          // GT patches are the first np candidates
-        n1 = fmaf(p1[d], p1[d], n1);
-        n2 = fmaf(p2[d], p2[d], n2);
-      }
-  p1[BB_D] = p2[BB_D] = 0.f;
+      for (int kx = 0; kx < 3; ++kx)
+        p[c * 9 + ky * 3 + kx] = live ? sr[(((size_t)b * 3 + c) * H + py * 3 + ky) * W + px * 3 + kx] : 0.f;
+  float f1[DP], f2[DP];
+  bb_features<GRAM>(p, f1);
+  float n1 = 0.f, n2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    if (d >= D) f1[d] = 0.f;
+    f2[d] = (live && d < D) ? cand[((size_t)b * ncand + q) * D + d] : 0.f;      // GT features are the first np candidates
+    n1 = fmaf(f1[d], f1[d], n1);
+    n2 = fmaf(f2[d], f2[d], n2);
+  }
   float best = 3.4e38f;
   int bi = 0x7fffffff;
   for (int j0 = 0; j0 < ncand; j0 += BB_CH) {
     __syncthreads();
-    for (int i = threadIdx.x; i < BB_CH * (BB_D + 1); i += BB_NT) {
-      const int j = i / (BB_D + 1), d = i - j * (BB_D + 1);
-      sc[j][d] = (j0 + j < ncand && d < BB_D) ? cand[((size_t)b * ncand + j0 + j) * BB_D + d] : 0.f;
+    for (int i = threadIdx.x; i < BB_CH * DP; i += BB_NT) {
+      const int j = i / DP, d = i - j * DP;
+      sc[j][d] = (j0 + j < ncand && d < D) ? cand[((size_t)b * ncand + j0 + j) * D + d] : 0.f;
     }
     for (int j = threadIdx.x; j < BB_CH; j += BB_NT) sn[j] = (j0 + j < ncand) ? cnrm[(size_t)b * ncand + j0 + j] : 0.f;
     __syncthreads();
@@ -87,12 +114,12 @@ __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict
     for (int j = part; j < nj; j += BB_SPLIT) {
       float d1 = 0.f, d2 = 0.f;
 #pragma unroll
-      for (int d4 = 0; d4 < (BB_D + 1) / 4; ++d4) {
+      for (int d4 = 0; d4 < DP / 4; ++d4) {
         const f32x4 cv = *reinterpret_cast<const f32x4*>(&sc[j][4 * d4]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          d1 = fmaf(p1[4 * d4 + e], cv[e], d1);
-          d2 = fmaf(p2[4 * d4 + e], cv[e], d2);
+          d1 = fmaf(f1[4 * d4 + e], cv[e], d1);
+          d2 = fmaf(f2[4 * d4 + e], cv[e], d2);
         }
       }
       const float cn = sn[j];
@@ -112,20 +139,36 @@ __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict
       if (s < best || (s == best && i2 < bi)) { best = s; bi = i2; }
     }
     ind_out[(size_t)b * np + q] = bi;
-    const float* sel = cand + ((size_t)b * ncand + bi) * BB_D;
+    const float* sel = cand + ((size_t)b * ncand + bi) * D;
+    float gf[D];                                          // d(loss)/d(feature)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float df = f1[d] - sel[d];
+      if (l2) { lsum = fmaf(df, df, lsum); gf[d] = 2.f * df * inv_n; }
+      else { lsum += fabsf(df); gf[d] = (df > 0.f ? inv_n : (df < 0.f ? -inv_n : 0.f)); }
+    }
+    float gp[BB_P];                                       // d(loss)/d(patch pixels)
+    if (GRAM) {                                           // G = F F^T / 27  ->  dF = (dG + dG^T) F / 27
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          float s = 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) s = fmaf(gf[a * 3 + c] + gf[c * 3 + a], p[c * 9 + k], s);
+          gp[a * 9 + k] = s / 27.f;
+        }
+    } else {
+#pragma unroll
+      for (int d = 0; d < BB_P; ++d) gp[d] = gf[d < D ? d : 0];
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int d = c * 9 + ky * 3 + kx;
-          const float df = p1[d] - sel[d];
-          float gv;
-          if (l2) { lsum = fmaf(df, df, lsum); gv = 2.f * df * inv_n; }
-          else { lsum += fabsf(df); gv = (df > 0.f ? inv_n : (df < 0.f ? -inv_n : 0.f)); }
-          dsr[(((size_t)b * 3 + c) * H + py * 3 + ky) * W + px * 3 + kx] = gv;
-        }
+        for (int kx = 0; kx < 3; ++kx)
+          dsr[(((size_t)b * 3 + c) * H + py * 3 + ky) * W + px * 3 + kx] = gp[c * 9 + ky * 3 + kx];
   }
   const float tot = block_sum<BB_NT>(lsum, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = tot * inv_n;
@@ -134,28 +177,37 @@ __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict
 }  // namespace
 
 SST_API int sst_bb_blocks(int B, int H, int W) { return B * (((H / 3) * (W / 3) + BB_Q - 1) / BB_Q); }
+SST_API int sst_bb_feature_dim(int gram) { return gram ? 9 : BB_P; }
 
-// img [B,3,H,W] (H, W multiples of 3) -> rows [cand_off, cand_off + (H/3)(W/3)) of cand [B, ncand_total, 27] and cnrm [B, ncand_total]
-SST_API int sst_bb_patches(const float* img, float* cand, float* cnrm, int B, int H, int W, int ncand_total, int cand_off,
+// img [B,3,H,W] (H, W multiples of 3) -> rows [cand_off, cand_off + (H/3)(W/3)) of cand [B, ncand_total, D] and cnrm
+// [B, ncand_total]; D = sst_bb_feature_dim(gram): the raw 27-vector (BestBuddyLoss) or the 3x3 gram matrix (GramLoss).
+SST_API int sst_bb_patches(const float* img, float* cand, float* cnrm, int B, int H, int W, int ncand_total, int cand_off, int gram,
                            void* stream) {
   SST_REQUIRE(img && cand && cnrm && B > 0 && H >= 3 && W >= 3 && H % 3 == 0 && W % 3 == 0 &&
                   cand_off >= 0 && cand_off + (H / 3) * (W / 3) <= ncand_total, "sst_bb_patches: bad argument");
   const int total = B * (H / 3) * (W / 3);
-  bb_patches_kernel<<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(img, cand, cnrm, B, H, W, ncand_total, cand_off);
+  if (gram)
+    bb_patches_kernel<1><<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(img, cand, cnrm, B, H, W, ncand_total, cand_off);
+  else
+    bb_patches_kernel<0><<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(img, cand, cnrm, B, H, W, ncand_total, cand_off);
   SST_LAUNCH_CHECK("bb_patches_kernel");
   return SST_OK;
 }
 
-// sr [B,3,H,W]; cand / cnrm: candidate table whose first (H/3)(W/3) rows are the full-resolution GT patches.
-// ind [B, nP] int32; dsr [B,3,H,W] = d(loss)/d(sr) for loss = sum(partials) (criterion mean over B*nP*27 elements);
+// sr [B,3,H,W]; cand / cnrm: candidate table whose first (H/3)(W/3) rows are the full-resolution GT features.
+// ind [B, nP] int32; dsr [B,3,H,W] = d(loss)/d(sr) for loss = sum(partials) (criterion mean over B*nP*D elements);
 // partials [sst_bb_blocks(B,H,W)].
 SST_API int sst_bb_match(const float* sr, const float* cand, const float* cnrm, int* ind, float* dsr, float* partials, int B, int H,
-                         int W, int ncand, float alpha, float beta, int criterion_l2, void* stream) {
+                         int W, int ncand, float alpha, float beta, int criterion_l2, int gram, void* stream) {
   SST_REQUIRE(sr && cand && cnrm && ind && dsr && partials && B > 0 && H >= 3 && W >= 3 && H % 3 == 0 && W % 3 == 0 &&
                   ncand >= (H / 3) * (W / 3), "sst_bb_match: bad argument");
-  const float inv_n = 1.f / ((float)B * (H / 3) * (W / 3) * BB_D);
-  bb_match_kernel<<<sst_bb_blocks(B, H, W), BB_NT, 0, sst_stream(stream)>>>(sr, cand, cnrm, ind, dsr, partials, B, H, W, ncand, alpha,
-                                                                            beta, criterion_l2, inv_n);
+  const float inv_n = 1.f / ((float)B * (H / 3) * (W / 3) * sst_bb_feature_dim(gram));
+  if (gram)
+    bb_match_kernel<1><<<sst_bb_blocks(B, H, W), BB_NT, 0, sst_stream(stream)>>>(sr, cand, cnrm, ind, dsr, partials, B, H, W, ncand,
+                                                                                 alpha, beta, criterion_l2, inv_n);
+  else
+    bb_match_kernel<0><<<sst_bb_blocks(B, H, W), BB_NT, 0, sst_stream(stream)>>>(sr, cand, cnrm, ind, dsr, partials, B, H, W, ncand,
+                                                                                 alpha, beta, criterion_l2, inv_n);
   SST_LAUNCH_CHECK("bb_match_kernel");
   return SST_OK;
 }

@@ -199,9 +199,9 @@ def _torch_bicubic_taps(in_size: int, out_size: int, device):
 
 class _BestBuddyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gt, alpha, beta, l2, cache):
+    def forward(ctx, x, gt, alpha, beta, l2, cache, gram=0):
         if x.dtype != torch.float32 or x.shape != gt.shape or x.dim() != 4 or x.shape[1] != 3:
-            raise _abi.HipPathError("BestBuddyLoss: fp32 [B,3,H,W] pairs")
+            raise _abi.HipPathError("BestBuddyLoss / GramLoss: fp32 [B,3,H,W] pairs")
         B, _, H, W = x.shape
         if H % 12 or W % 12:
             raise _abi.HipPathError("BestBuddyLoss: H and W must be multiples of 12 (3x3 patches at scales 1, 1/2, 1/4)")
@@ -213,24 +213,24 @@ class _BestBuddyFn(torch.autograd.Function):
             cache["taps"] = [(_torch_bicubic_taps(H, H // s, dev), _torch_bicubic_taps(W, W // s, dev)) for s in (2, 4)]
         nps = [(H // s // 3) * (W // s // 3) for s in (1, 2, 4)]
         ncand = sum(nps)
-        cand = torch.empty(B, ncand, 27, device=dev, dtype=torch.float32)
+        cand = torch.empty(B, ncand, lib.sst_bb_feature_dim(int(gram)), device=dev, dtype=torch.float32)
         cnrm = torch.empty(B, ncand, device=dev, dtype=torch.float32)
         st = _abi.stream_ptr()
-        _abi.check(lib.sst_bb_patches(_abi.ptr(gt), _abi.ptr(cand), _abi.ptr(cnrm), B, H, W, ncand, 0, st), "sst_bb_patches")
+        _abi.check(lib.sst_bb_patches(_abi.ptr(gt), _abi.ptr(cand), _abi.ptr(cnrm), B, H, W, ncand, 0, int(gram), st), "sst_bb_patches")
         off = nps[0]
         for k, s in enumerate((2, 4)):                       # GT at 1/2 and 1/4 resolution (torch bicubic), then its patches
             (wy, iy), (wx, ix) = cache["taps"][k]
             small = torch.empty(B, 3, H // s, W // s, device=dev, dtype=torch.float32)
             _abi.check(lib.sst_bicubic(_abi.ptr(gt), _abi.ptr(small), _abi.ptr(wy), _abi.ptr(iy), _abi.ptr(wx), _abi.ptr(ix), B * 3, H, W,
                                        H // s, W // s, 4, 4, 0, st), "sst_bicubic")
-            _abi.check(lib.sst_bb_patches(_abi.ptr(small), _abi.ptr(cand), _abi.ptr(cnrm), B, H // s, W // s, ncand, off, st),
+            _abi.check(lib.sst_bb_patches(_abi.ptr(small), _abi.ptr(cand), _abi.ptr(cnrm), B, H // s, W // s, ncand, off, int(gram), st),
                        "sst_bb_patches")
             off += nps[k + 1]
         ind = torch.empty(B, nps[0], device=dev, dtype=torch.int32)
         dsr = torch.empty_like(x)
         partials = torch.empty(lib.sst_bb_blocks(B, H, W), device=dev, dtype=torch.float32)
         _abi.check(lib.sst_bb_match(_abi.ptr(x), _abi.ptr(cand), _abi.ptr(cnrm), _abi.ptr(ind), _abi.ptr(dsr), _abi.ptr(partials), B, H, W,
-                                    ncand, float(alpha), float(beta), int(l2), st), "sst_bb_match")
+                                    ncand, float(alpha), float(beta), int(l2), int(gram), st), "sst_bb_match")
         ctx.save_for_backward(dsr)
         ctx.mark_non_differentiable(ind)
         return partials.sum(), ind
@@ -238,7 +238,7 @@ class _BestBuddyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _grad_ind):
         (dsr,) = ctx.saved_tensors
-        return dsr * grad_out, None, None, None, None, None
+        return dsr * grad_out, None, None, None, None, None, None
 
 
 class BestBuddyLoss(nn.Module):
@@ -259,6 +259,27 @@ class BestBuddyLoss(nn.Module):
 
     def forward(self, x, gt):
         loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache)
+        self.last_index = ind
+        return loss
+
+
+class GramLoss(nn.Module):
+    """Reference loss.py:145-228 (best-buddy matching on the 3x3 gram matrix of every 3x3 patch) on the HIP path.  Same
+    constructor; supported: ksize 3, dist_norm 'l2', criterion 'l1' or 'l2' / 'mse'."""
+
+    def __init__(self, alpha: float = 1.0, beta: float = 1.0, ksize: int = 3, dist_norm: str = "l2", criterion: str = "l1") -> None:
+        super().__init__()
+        if (ksize, dist_norm) != (3, "l2"):
+            raise NotImplementedError("GramLoss on the HIP path: ksize=3, dist_norm='l2' only")
+        if criterion not in ("l1", "l2", "mse"):
+            raise NotImplementedError("%s criterion has not been implmented." % criterion)
+        self.alpha, self.beta, self.ksize, self.dist_norm = alpha, beta, ksize, dist_norm
+        self.l2 = criterion != "l1"
+        self._cache = {}
+        self.last_index = None
+
+    def forward(self, x, gt):
+        loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache, 1)
         self.last_index = ind
         return loss
 

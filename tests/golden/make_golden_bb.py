@@ -39,6 +39,22 @@ def main():
         arrs[f"{name}/gt2"], arrs[f"{name}/gt4"] = gt2.numpy(), gt4.numpy()
         arrs[f"{name}/ind"] = top2.indices[..., 0].numpy().astype(np.int32)
         arrs[f"{name}/margin"] = (top2.values[..., 1] - top2.values[..., 0]).numpy()
+        # GramLoss (loss.py:145-228) on the same pair
+        for crit in ("l1", "l2"):
+            gm = rloss.GramLoss(criterion=crit)
+            gl = gm(x, gt)
+            (ggx,) = torch.autograd.grad(gl, x)
+            arrs[f"{name}/gram/{crit}/loss"] = gl.detach().numpy()
+            arrs[f"{name}/gram/{crit}/grad"] = ggx.numpy()
+        with torch.no_grad():
+            gm = rloss.GramLoss()
+            q1, q2 = gm.compute_patches(x), gm.compute_patches(gt)
+            qcat = torch.cat([q2, gm.compute_patches(gt2), gm.compute_patches(gt4)], 1)
+            gs = rutils.batch_pairwise_distance(q1, qcat, "l2") + rutils.batch_pairwise_distance(q2, qcat, "l2")
+            gtop = torch.topk(gs, 2, dim=2, largest=False)
+        arrs[f"{name}/gram/ind"] = gtop.indices[..., 0].numpy().astype(np.int32)
+        arrs[f"{name}/gram/margin"] = (gtop.values[..., 1] - gtop.values[..., 0]).numpy()
+        arrs[f"{name}/gram/p1"] = q1.numpy()
     save("bestbuddy", **arrs)
 
 
