@@ -94,13 +94,15 @@ def allreduce_module_grads(module, pg=None, buckets: int = 1, force: bool = Fals
         return allreduce_grads(ps, pg, buckets, force)
     n = flat.numel()
     step = (n + buckets - 1) // buckets
+    # RCCL averages inside the collective (one elementwise pass less); gloo (CPU tests) has no AVG: sum, then scale
+    avg = td.get_backend(pg) == "nccl" and hasattr(td.ReduceOp, "AVG")
     handles = []
     for i in range(0, n, step):
         sl = flat[i:i + step]
-        handles.append((td.all_reduce(sl, op=td.ReduceOp.SUM, group=pg, async_op=True), sl))
+        handles.append((td.all_reduce(sl, op=td.ReduceOp.AVG if avg else td.ReduceOp.SUM, group=pg, async_op=True), sl))
     for h, sl in handles:
         h.wait()
-        if world > 1:
+        if world > 1 and not avg:
             sl.mul_(1.0 / world)
 
 
