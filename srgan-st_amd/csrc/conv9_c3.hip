@@ -34,7 +34,7 @@ struct WgC3Args {
 // NU = (ky, channel-fragment) units per wave, compile-time so that the unit loops unroll without branches
 // (only the LAST unit of a wave can be missing: 9*nfrag units are dealt round-robin over 4 waves).
 template <int NU>
-__global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
+__global__ __launch_bounds__(CONV_NT, (NU <= 5 ? 2 : 1)) void wgrad_c3_kernel(WgC3Args a) {   // <= 256 VGPRs: 2 workgroups per CU
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave id in an SGPR: everything derived from it stays scalar
   const int li = lane & 31, lh = lane >> 5;
@@ -98,6 +98,55 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_c3_kernel(WgC3Args a) {
     }
     __syncthreads();
     const int npair = (tw + 1) >> 1;
+    if (tw == TXMAX) {
+      // Full-width segment (the 96-px case): every LDS address is a per-unit base (computed once per row) plus a compile-time
+      // offset, so the unrolled pair loop issues no address arithmetic at all - with ~40 VALU instructions per 5 MFMAs the
+      // generic loop below is issue-bound (PMC: MFMA pipe 35 % busy, waves 28 % of their time issuing non-MFMA work).
+      const float* pa[NU];
+      const float* pb[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        pa[u] = sB + lh * CL + u_fr[u];
+        pb[u] = sS + ry * RS + u_br[u] + 8 + 3 * lh + (a.kind ? li : 26 - li);
+      }
+      float av[NU], bv[NU], an[NU], bn[NU];
+#define SST_C3_LOAD(KK, A_, B_)                                                         \
+      _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                   \
+        if (u < NU - 1 || last_ok) {                                                     \
+          A_[u] = pa[u][(KK) * 2 * CL];                                                  \
+          B_[u] = pb[u][(KK) * 6];                                                       \
+        }                                                                                \
+      }
+#define SST_C3_MMA(A_, B_)                                                               \
+      _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                   \
+        if (u < NU - 1 || last_ok) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u], B_[u], acc[u], 0, 0, 0); \
+      }
+      // CL is a runtime value (C-dependent), so the A offsets are (KK * 2) * CL: one scalar multiply-add per load at most,
+      // the B offsets are immediates
+      // 6 blocks of 8 pairs: inside a block the offsets are compile-time, between blocks the 2*NU base pointers advance
+      // (full unrolling lets the scheduler hoist every load of the row: 490 VGPRs, one wave per SIMD)
+      constexpr int BLK = 4;
+      static_assert((TXMAX / 2) % BLK == 0, "pair blocks");
+      SST_C3_LOAD(0, av, bv)
+      for (int k0 = 0; k0 < TXMAX / 2; k0 += BLK) {
+#pragma unroll
+        for (int kk = 0; kk < BLK; kk += 2) {
+          SST_C3_LOAD(kk + 1, an, bn)
+          SST_C3_MMA(av, bv)
+          if (kk + 2 < BLK) { SST_C3_LOAD(kk + 2, av, bv) }
+          else if (k0 + BLK < TXMAX / 2) { SST_C3_LOAD(BLK, av, bv) }      // first pair of the next block
+          SST_C3_MMA(an, bn)
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          pa[u] += BLK * 2 * CL;
+          pb[u] += BLK * 6;
+        }
+      }
+#undef SST_C3_LOAD
+#undef SST_C3_MMA
+      continue;
+    }
     // operands of pair kk+1 are read from LDS while the (<= MAXU) MFMAs of pair kk run
     float av[NU], bv[NU];
     auto load_pair = [&](int kk, float (&A)[NU], float (&Bv)[NU]) {
