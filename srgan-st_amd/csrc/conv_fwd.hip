@@ -217,7 +217,7 @@ __device__ __forceinline__ void conv_fwd_body(const Conv3Args& a, const int bx, 
 }
 
 template <int KS, int S>
-__global__ __launch_bounds__(CONV_NT) void conv_fwd_kernel(Conv3Args a) {
+__global__ __launch_bounds__(CONV_NT, (KS == 3 && S == 1 ? 5 : 3)) void conv_fwd_kernel(Conv3Args a) {   // 3x3 s1: <= 96 VGPRs, 5 workgroups per CU (measured +5..10 % on the dgrad shapes); the others are LDS-limited to 3
   conv_fwd_body<KS, S>(a, blockIdx.x, blockIdx.y);
 }
 
@@ -229,7 +229,7 @@ struct S2Classes {
   int nh[4], nw[4], tiles[4];
   int tile_base[4];          // first partial tile of the class (epi_partial is [sum of tiles][3][Cout])
 };
-__global__ __launch_bounds__(CONV_NT) void conv_s2dgrad_kernel(Conv3Args a, S2Classes c) {
+__global__ __launch_bounds__(CONV_NT, 5) void conv_s2dgrad_kernel(Conv3Args a, S2Classes c) {
   const int cls = blockIdx.z;
   if ((int)blockIdx.x >= c.tiles[cls]) return;
   a.wp += c.wp_off[cls];

@@ -11,7 +11,7 @@ namespace {
 constexpr int T2 = 8;             // 8 x 8 output pixels
 
 template <int S>
-__global__ __launch_bounds__(CONV_NT) void conv_fwd2_kernel(Conv3Args a) {
+__global__ __launch_bounds__(CONV_NT, 3) void conv_fwd2_kernel(Conv3Args a) {   // <= 168 VGPRs: three workgroups per CU
   constexpr int KS = 3;
   constexpr int PW = (T2 - 1) * S + KS, PH = PW, NP = PW * PH;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // max(NP*LDSC, 4*32*33) floats
