@@ -218,6 +218,14 @@ int sst_slab_reduce(const float* slabs, float* out, int nslab, int64_t n, int ac
  * clamp_(0,1) model.py:150 fused with the NCHW->NHWC hand-off and the conv3 bias gradient.
  * pixel criterion config.py:88-90 (mode 0 MSE / 1 L1); BCEWithLogits config.py:71-73, train.py:113-161. */
 int sst_transpose(const float* src, float* dst, int B, int C, int H, int W, int to_nchw, void* stream);
+/* feature criterion on activated, per-channel-affine taps (ContentLossDiscriminator loss.py:231-289: BatchNorm(eval) + LeakyReLU
+ * outputs of the discriminator): f(v) = act(v*scale[c]+shift[c]) with slope activation, loss = mean crit(f(x) - f(gt)) over a
+ * [rows, C] tensor (mode 0 MSE, 1 L1); bwd: dx (+)= scale_host * scale_dev * dloss/dx */
+int sst_feat_loss_fwd(const float* x, const float* gt, const float* scale, const float* shift, float slope, int C,
+                      float* loss, float* partials, unsigned* counter, int64_t n, int mode, void* stream);
+int sst_feat_loss_bwd(const float* x, const float* gt, const float* scale, const float* shift, float slope, int C,
+                      float* dx, const float* scale_dev, float scale_host, int accumulate, int64_t n, int mode,
+                      void* stream);
 /* VGG19 feature stack pieces of ContentLossVGG (loss.py:11-70): ImageNet normalise fused with the layout change,
  * ReLU+MaxPool2d(2) forward/backward; the feature criterion is sst_pixel_loss_* with mode |= 2 (criterion on relu(x)). */
 int sst_transpose_affine(const float* src, float* dst, int B, int C, int H, int W, int to_nchw,

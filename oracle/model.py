@@ -155,3 +155,40 @@ def param_keys(sd):
     """Keys that are nn.Parameters (everything except BN buffers), in state-dict order."""
     return [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var")
                                   or k.endswith("num_batches_tracked"))]
+
+
+# ---- ContentLossDiscriminator (reference loss.py:231-289): feature taps of the discriminator in eval mode
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def discriminator_features(sd, x, taps):
+    """Outputs of the modules `features.<idx>` (idx in taps; LeakyReLU outputs) of the discriminator in eval mode
+    (loss.py:264-277: create_feature_extractor(...).eval()) -> {idx: tensor}."""
+    out, h = {}, x
+    for ci, bi, cm, om, s in D_PLAN:
+        h = F.conv2d(h, sd[f"features.{ci}.weight"], sd.get(f"features.{ci}.bias"), s, 1)
+        act_idx = ci + 1
+        if bi is not None:
+            h = _bn(h, sd, f"features.{bi}", False, None)
+            act_idx = bi + 1
+        h = F.leaky_relu(h, 0.2)
+        if act_idx in taps:
+            out[act_idx] = h
+        if act_idx >= max(taps):
+            break
+    return out
+
+
+def disc_content_loss(sd, x, gt, layers, criterion="mse"):
+    """loss.py:279-289: sum_layer weight * criterion(feat(normalize(x)), feat(normalize(gt)))."""
+    mean = torch.tensor(IMAGENET_MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=x.dtype).view(1, 3, 1, 1)
+    taps = {int(k.split(".")[1]): float(v) for k, v in layers.items()}
+    fx = discriminator_features(sd, (x - mean) / std, set(taps))
+    fg = discriminator_features(sd, (gt - mean) / std, set(taps))
+    crit = F.mse_loss if criterion in ("mse", "l2") else F.l1_loss
+    loss = 0.0
+    for t, w in taps.items():
+        loss = loss + w * crit(fx[t], fg[t])
+    return loss

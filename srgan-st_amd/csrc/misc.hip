@@ -172,6 +172,50 @@ __global__ __launch_bounds__(NT) void pixel_loss_bwd_kernel(const float* __restr
   }
 }
 
+// ---- feature criterion on activated, per-channel-affine features (ContentLossDiscriminator, loss.py:231-289: taps after
+// BatchNorm(eval) + LeakyReLU of the discriminator):  f(v) = act(v*scale[c] + shift[c]),  act(z) = z > 0 ? z : slope*z,
+// loss = mean crit(f(x) - f(gt)) over [rows, C] tensors (mode 0 = MSE, 1 = L1); the taps hold the conv outputs v.
+__global__ __launch_bounds__(NT) void feat_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float slope, int C, float* __restrict__ loss, float* __restrict__ partials,
+                                                           unsigned* __restrict__ counter, int64_t n, int mode) {
+  __shared__ float red[NT / 64];
+  float s = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const int c = (int)(i % C);
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    float a = fmaf(x[i], sc, sh), b = fmaf(gt[i], sc, sh);
+    a = a > 0.f ? a : a * slope;
+    b = b > 0.f ? b : b * slope;
+    const float d = a - b;
+    s += mode == 0 ? d * d : fabsf(d);
+  }
+  s = block_sum<NT>(s, red);
+  __shared__ unsigned s_flag;
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+  float tot;
+  if (last_block_total<NT>(partials, counter, gridDim.x, &s_flag, red, tot) && threadIdx.x == 0) loss[0] = tot / (float)n;
+}
+
+// dx (+)= scale_host * scale_dev * d(loss)/dx   (gradient w.r.t. the conv output x; gt is a constant)
+__global__ __launch_bounds__(NT) void feat_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float slope, int C, float* __restrict__ dx, const float* __restrict__ scale_dev,
+                                                           float scale_host, int accumulate, int64_t n, int mode) {
+  float k = scale_host / (float)n;
+  if (scale_dev) k *= scale_dev[0];
+  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const int c = (int)(i % C);
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    const float za = fmaf(x[i], sc, sh), zb = fmaf(gt[i], sc, sh);
+    const float a = za > 0.f ? za : za * slope, b = zb > 0.f ? zb : zb * slope;
+    const float d = a - b;
+    float g = mode == 0 ? 2.f * d * k : (d > 0.f ? k : (d < 0.f ? -k : 0.f));
+    g *= (za > 0.f ? 1.f : slope) * sc;
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
+
 // ---- BCEWithLogits(mean) against a constant target t:  l = max(x,0) - x t + log1p(exp(-|x|))
 // single workgroup (logits are [B,1]); dlogit = scale * (sigmoid(x) - t) / n
 __global__ __launch_bounds__(NT) void bce_fwd_bwd_kernel(const float* __restrict__ x, float target, float* __restrict__ loss,
@@ -276,6 +320,26 @@ SST_API int sst_pixel_loss_bwd(const float* x, const float* gt, float* dx, const
   SST_REQUIRE(x && gt && dx && n > 0 && mode >= 0 && mode <= 3, "sst_pixel_loss_bwd: bad argument");
   pixel_loss_bwd_kernel<<<grid_for(n), NT, 0, sst_stream(stream)>>>(x, gt, dx, scale_dev, scale_host, accumulate, n, mode);
   SST_LAUNCH_CHECK("pixel_loss_bwd_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_feat_loss_fwd(const float* x, const float* gt, const float* scale, const float* shift, float slope, int C, float* loss,
+                              float* partials, unsigned* counter, int64_t n, int mode, void* stream) {
+  SST_REQUIRE(x && gt && loss && partials && counter && n > 0 && C > 0 && n % C == 0 && (mode == 0 || mode == 1) &&
+                  ((scale == nullptr) == (shift == nullptr)), "sst_feat_loss_fwd: bad argument");
+  feat_loss_fwd_kernel<<<sst_pixel_loss_blocks(n), NT, 0, sst_stream(stream)>>>(x, gt, scale, shift, slope, C, loss, partials, counter, n,
+                                                                                 mode);
+  SST_LAUNCH_CHECK("feat_loss_fwd_kernel");
+  return SST_OK;
+}
+
+SST_API int sst_feat_loss_bwd(const float* x, const float* gt, const float* scale, const float* shift, float slope, int C, float* dx,
+                              const float* scale_dev, float scale_host, int accumulate, int64_t n, int mode, void* stream) {
+  SST_REQUIRE(x && gt && dx && n > 0 && C > 0 && n % C == 0 && (mode == 0 || mode == 1) && ((scale == nullptr) == (shift == nullptr)),
+              "sst_feat_loss_bwd: bad argument");
+  feat_loss_bwd_kernel<<<grid_for(n), NT, 0, sst_stream(stream)>>>(x, gt, scale, shift, slope, C, dx, scale_dev, scale_host, accumulate, n,
+                                                                   mode);
+  SST_LAUNCH_CHECK("feat_loss_bwd_kernel");
   return SST_OK;
 }
 

@@ -81,6 +81,8 @@ SIGNATURES = {
     "sst_pixel_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int64, c_int, P]),
     "sst_bce_logits": (c_int, [P, c_float, P, P, P, c_float, c_int, P]),
     "sst_bicubic": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_feat_loss_fwd": (c_int, [P, P, P, P, c_float, c_int, P, P, P, c_int64, c_int, P]),
+    "sst_feat_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, P, P, c_float, c_int, c_int64, c_int, P]),
     "sst_bb_blocks": (c_int, [c_int, c_int, c_int]),
     "sst_bb_feature_dim": (c_int, [c_int]),
     "sst_bb_patches": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -2,6 +2,8 @@
 
 StructureTensorLoss  <- reference loss.py:380-413 (+ utils.py:194-280), kernels csrc/st_loss.hip
 ContentLossVGG       <- reference loss.py:11-70, in vgg_loss.py (re-exported here)
+BestBuddyLoss / GramLoss <- reference loss.py:78-228, kernels csrc/bb_loss.hip
+ContentLossDiscriminator <- reference loss.py:231-289, in disc_loss.py (re-exported here)
 """
 from __future__ import annotations
 
@@ -327,3 +329,4 @@ class BCEWithLogitsLoss(nn.Module):
 
 
 from .vgg_loss import ContentLossVGG  # noqa: E402,F401  (reference loss.py:11)
+from .disc_loss import ContentLossDiscriminator  # noqa: E402,F401  (reference loss.py:231)
