@@ -246,18 +246,22 @@ int sst_bce_logits(const float* logits, float target, float* loss, float* dlogit
  * tables: x [planes,H,W] -> y [planes,oh,ow]; wy/iy [oh,Ty], wx/ix [ow,Tx]; round_grid: round to the 1/255 grid (no clamp) */
 int sst_bicubic(const float* x, float* y, const float* wy, const int* iy, const float* wx, const int* ix,
                 int64_t planes, int H, int W, int oh, int ow, int Ty, int Tx, int round_grid, void* stream);
-/* ---- best-buddy losses (loss.py:78-142 BestBuddyLoss, loss.py:145-228 GramLoss; ksize 3, stride 3, pad 0, squared-L2
- * matching):
+/* ---- best-buddy losses (loss.py:78-142 BestBuddyLoss, loss.py:145-228 GramLoss, loss.py:292-375
+ * PatchwiseStructureTensorLoss; ksize 3, stride 3, pad 0, squared-L2 matching):
  * sst_bb_patches cuts an image [B,3,H,W] into 27-vectors (unfold order) + squared norms inside the candidate table
  * cand [B,ncand,27] / cnrm [B,ncand]; sst_bb_match pairs every SR patch with its best candidate (first minimum of
  * alpha*d(sr_i,c_j) + beta*d(gt_i,c_j), d = clamped expanded squared distance of utils.py:173-187) and produces the selected
  * indices, d(loss)/d(sr) and per-workgroup partial sums of the L1 / L2 criterion (loss = sum of partials) */
 int sst_bb_blocks(int B, int H, int W);
-int sst_bb_feature_dim(int gram);   /* 27 (raw patch, BestBuddyLoss) or 9 (3x3 gram matrix of the patch, GramLoss loss.py:145-228) */
+/* feature mode: 0 raw patch (27, BestBuddyLoss), 1 gram matrix of the patch (9, GramLoss loss.py:145-228), 2 normalised
+ * structure tensor of the 3x3 gray patch (27, PatchwiseStructureTensorLoss loss.py:292-375; st_mats = device [Ax 81][Ay 81][K 81],
+ * the three 9x9 maps of utils.py:212-233 restricted to a zero-padded 3x3 image) */
+int sst_bb_feature_dim(int mode);
 int sst_bb_patches(const float* img, float* cand, float* cnrm, int B, int H, int W, int ncand_total, int cand_off,
-                   int gram, void* stream);
+                   int mode, const float* st_mats, void* stream);
 int sst_bb_match(const float* sr, const float* cand, const float* cnrm, int* ind, float* dsr, float* partials, int B,
-                 int H, int W, int ncand, float alpha, float beta, int criterion_l2, int gram, void* stream);
+                 int H, int W, int ncand, float alpha, float beta, int criterion_l2, int mode, const float* st_mats,
+                 void* stream);
 int sst_weighted_sum(const float* const* terms, const float* weights, int n, float* out, float* weighted,
                      void* stream);
 

@@ -68,3 +68,26 @@ def gram_loss(x, gt, alpha=1.0, beta=1.0, ksize=3, dist_norm="l2", criterion="l1
     sel = torch.gather(cat, 1, ind.unsqueeze(-1).expand(-1, -1, p1.shape[2]))
     loss = F.l1_loss(p1, sel) if criterion == "l1" else F.mse_loss(p1, sel)
     return loss, ind, score
+
+
+# ---- PatchwiseStructureTensorLoss (reference loss.py:292-375): the same matching on the normalised structure tensor of every
+# 3x3 patch (gray -> structure_tensor(sigma, rho) with zero 'same' padding inside the patch -> normalize; 3 x 9 = 27 features)
+def st_patches(img, sigma=0.5, rho=2.0, ksize=3):
+    from . import st as ost
+    B = img.shape[0]
+    p = F.unfold(img, kernel_size=ksize, stride=ksize).permute(0, 2, 1).reshape(-1, 3, ksize, ksize)     # [B*nP, 3, k, k]
+    S = ost.structure_tensor(ost.grayscale(p), sigma, rho)                                              # [B*nP, 3, k, k]
+    return ost.normalize(S).reshape(B, -1, 3 * ksize * ksize)
+
+
+def patchwise_st_loss(x, gt, sigma=0.5, rho=2.0, alpha=1.0, beta=1.0, ksize=3, dist_norm="l2", criterion="l1"):
+    p1, p2 = st_patches(x, sigma, rho, ksize), st_patches(gt, sigma, rho, ksize)
+    gt2 = F.interpolate(gt, scale_factor=0.5, mode="bicubic", align_corners=False)
+    gt4 = F.interpolate(gt, scale_factor=0.25, mode="bicubic", align_corners=False)
+    cat = torch.cat([p2, st_patches(gt2, sigma, rho, ksize), st_patches(gt4, sigma, rho, ksize)], 1)
+    dist = pairwise_sq_l2 if dist_norm == "l2" else pairwise_l1
+    score = alpha * dist(p1, cat) + beta * dist(p2, cat)
+    ind = torch.min(score, dim=2)[1]
+    sel = torch.gather(cat, 1, ind.unsqueeze(-1).expand(-1, -1, p1.shape[2]))
+    loss = F.l1_loss(p1, sel) if criterion == "l1" else F.mse_loss(p1, sel)
+    return loss, ind, score

@@ -1,9 +1,11 @@
-// Best-buddy losses on the GPU: reference loss.py:78-142 BestBuddyLoss and loss.py:145-228 GramLoss (matching via
-// utils.py:157-191 batch_pairwise_distance).
+// Best-buddy losses on the GPU: reference loss.py:78-142 BestBuddyLoss, loss.py:145-228 GramLoss and loss.py:292-375
+// PatchwiseStructureTensorLoss (matching via utils.py:157-191 batch_pairwise_distance).
 //
 // The SR and GT images are cut into non-overlapping 3 x 3 patches (27-vectors F in unfold order c*9 + ky*3 + kx).  A patch's
-// FEATURE is the vector itself (BestBuddyLoss) or its 3x3 gram matrix G = F F^T / 27 with F viewed as [3 channels][9]
-// (GramLoss, 9-vector).  The candidate set is the GT features at scales 1, 1/2, 1/4; SR patch i is paired with the candidate j
+// FEATURE is the vector itself (BestBuddyLoss, mode 0), its 3x3 gram matrix G = F F^T / 27 with F viewed as [3 channels][9]
+// (GramLoss, mode 1, 9-vector) or the normalised structure tensor of the 3x3 gray patch (PatchwiseStructureTensorLoss, mode 2:
+// utils.py:212-239 on a 3x3 image = three fixed 9x9 linear maps: Ix = Ax g, Iy = Ay g, J = K (Ix^2, Iy^2, Ix Iy), then
+// S / sqrt(det S + 1e-12); 27-vector (Jxx, Jyy, Jxy) x 9 pixels).  The candidate set is the GT features at scales 1, 1/2, 1/4; SR patch i is paired with the candidate j
 // minimising   alpha * max(|f_sr_i|^2 + |c_j|^2 - 2 f_sr_i.c_j, 0) + beta * max(|f_gt_i|^2 + |c_j|^2 - 2 f_gt_i.c_j, 0)
 // (the reference's expanded squared distance, clamped; first minimum wins like torch.min) and the loss is the mean L1 (or L2)
 // between the SR features and their buddies.  Only that last criterion is differentiated (through the gram map for GramLoss).
@@ -20,9 +22,88 @@ constexpr int BB_P = 27;                                       // raw patch: 3 c
 constexpr int BB_Q = 32, BB_SPLIT = 8, BB_NT = BB_Q * BB_SPLIT;   // query patches x candidate splits per workgroup
 constexpr int BB_CH = 128;                                     // candidates per LDS chunk
 
+constexpr float BB_GW0 = 0.2989f, BB_GW1 = 0.587f, BB_GW2 = 0.114f;   // torchvision Grayscale (ITU-R 601), loss.py:341
+
+// normalised structure tensor of a 3x3 patch; mats = [Ax 81][Ay 81][K 81] (row-major [out pixel][in pixel]).
+// Also returns what the backward pass needs when `keep` is given: Ix, Iy, Jxx, Jyy, Jxy, r (9 each).
+__device__ __forceinline__ void bb_st_forward(const float (&p)[BB_P], const float* mats, float* f, float* keep) {
+  float g[9], ix[9], iy[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = BB_GW0 * p[k] + BB_GW1 * p[9 + k] + BB_GW2 * p[18 + k];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      a = fmaf(mats[i * 9 + k], g[k], a);
+      b = fmaf(mats[81 + i * 9 + k], g[k], b);
+    }
+    ix[i] = a;
+    iy[i] = b;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    float jxx = 0.f, jyy = 0.f, jxy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float kk = mats[162 + i * 9 + k];
+      jxx = fmaf(kk, ix[k] * ix[k], jxx);
+      jyy = fmaf(kk, iy[k] * iy[k], jyy);
+      jxy = fmaf(kk, ix[k] * iy[k], jxy);
+    }
+    const float r = 1.f / sqrtf(jxx * jyy - jxy * jxy + 1e-12f);
+    f[i] = jxx * r;
+    f[9 + i] = jyy * r;
+    f[18 + i] = jxy * r;
+    if (keep) {
+      keep[i] = ix[i]; keep[9 + i] = iy[i]; keep[18 + i] = jxx; keep[27 + i] = jyy; keep[36 + i] = jxy; keep[45 + i] = r;
+    }
+  }
+}
+
+// gp = (d feature / d patch)^T gf for the structure-tensor features (keep from bb_st_forward)
+__device__ __forceinline__ void bb_st_backward(const float* keep, const float* mats, const float* gf, float* gp) {
+  float dxx[9], dyy[9], dxy[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const float jxx = keep[18 + i], jyy = keep[27 + i], jxy = keep[36 + i], r = keep[45 + i];
+    const float a = gf[i], b = gf[9 + i], c = gf[18 + i];
+    const float t = -0.5f * (a * jxx + b * jyy + c * jxy) * r * r * r;        // through r = (det + eps)^(-1/2)
+    dxx[i] = a * r + t * jyy;
+    dyy[i] = b * r + t * jxx;
+    dxy[i] = c * r - 2.f * t * jxy;
+  }
+  float dix[9], diy[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    float pxx = 0.f, pyy = 0.f, pxy = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float kk = mats[162 + i * 9 + k];                               // K^T
+      pxx = fmaf(kk, dxx[i], pxx);
+      pyy = fmaf(kk, dyy[i], pyy);
+      pxy = fmaf(kk, dxy[i], pxy);
+    }
+    const float ix = keep[k], iy = keep[9 + k];
+    dix[k] = 2.f * ix * pxx + iy * pxy;
+    diy[k] = 2.f * iy * pyy + ix * pxy;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    float dg = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dg = fmaf(mats[i * 9 + k], dix[i], fmaf(mats[81 + i * 9 + k], diy[i], dg));   // Ax^T, Ay^T
+    gp[k] = BB_GW0 * dg;
+    gp[9 + k] = BB_GW1 * dg;
+    gp[18 + k] = BB_GW2 * dg;
+  }
+}
+
 template <int GRAM>
-__device__ __forceinline__ void bb_features(const float (&p)[BB_P], float* f) {   // f: 27 (raw) or 9 (gram) values
-  if (GRAM) {
+__device__ __forceinline__ void bb_features(const float (&p)[BB_P], float* f, const float* mats) {   // f: 27 (raw / st) or 9 (gram)
+  if (GRAM == 2) {
+    bb_st_forward(p, mats, f, nullptr);
+  } else if (GRAM == 1) {
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -40,8 +121,14 @@ __device__ __forceinline__ void bb_features(const float (&p)[BB_P], float* f) { 
 
 template <int GRAM>
 __global__ __launch_bounds__(256) void bb_patches_kernel(const float* __restrict__ img, float* __restrict__ out, float* __restrict__ nrm,
-                                                         int B, int H, int W, int ncand_total, int cand_off) {
-  constexpr int D = GRAM ? 9 : BB_P;
+                                                         int B, int H, int W, int ncand_total, int cand_off,
+                                                         const float* __restrict__ mats_g) {
+  constexpr int D = GRAM == 1 ? 9 : BB_P;
+  __shared__ float mats[243];
+  if (GRAM == 2) {
+    for (int i = threadIdx.x; i < 243; i += 256) mats[i] = mats_g[i];
+    __syncthreads();
+  }
   const int ph = H / 3, pw = W / 3, np = ph * pw;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < B * np; i += gridDim.x * 256) {
     const int b = i / np, pidx = i - b * np, py = pidx / pw, px = pidx - py * pw;
@@ -52,7 +139,7 @@ __global__ __launch_bounds__(256) void bb_patches_kernel(const float* __restrict
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) p[c * 9 + ky * 3 + kx] = img[(((size_t)b * 3 + c) * H + py * 3 + ky) * W + px * 3 + kx];
-    bb_features<GRAM>(p, f);
+    bb_features<GRAM>(p, f, mats);
     float* o = out + ((size_t)b * ncand_total + cand_off + pidx) * D;
     float s = 0.f;
 #pragma unroll
@@ -68,8 +155,14 @@ template <int GRAM>
 __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict__ sr, const float* __restrict__ cand,
                                                          const float* __restrict__ cnrm, int* __restrict__ ind_out,
                                                          float* __restrict__ dsr, float* __restrict__ partials, int B, int H, int W,
-                                                         int ncand, float alpha, float beta, int l2, float inv_n) {
-  constexpr int D = GRAM ? 9 : BB_P, DP = (D + 3) / 4 * 4;     // feature length, padded to 16-B rows in LDS
+                                                         int ncand, float alpha, float beta, int l2, float inv_n,
+                                                         const float* __restrict__ mats_g) {
+  constexpr int D = GRAM == 1 ? 9 : BB_P, DP = (D + 3) / 4 * 4;     // feature length, padded to 16-B rows in LDS
+  __shared__ float mats[243];
+  if (GRAM == 2) {
+    for (int i = threadIdx.x; i < 243; i += BB_NT) mats[i] = mats_g[i];
+    __syncthreads();
+  }
   __shared__ __attribute__((aligned(16))) float sc[BB_CH][DP];
   __shared__ float sn[BB_CH];
   __shared__ float sbest[BB_SPLIT][BB_Q];
@@ -91,7 +184,7 @@ __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict
       for (int kx = 0; kx < 3; ++kx)
         p[c * 9 + ky * 3 + kx] = live ? sr[(((size_t)b * 3 + c) * H + py * 3 + ky) * W + px * 3 + kx] : 0.f;
   float f1[DP], f2[DP];
-  bb_features<GRAM>(p, f1);
+  bb_features<GRAM>(p, f1, mats);
   float n1 = 0.f, n2 = 0.f;
 #pragma unroll
   for (int d = 0; d < DP; ++d) {
@@ -148,7 +241,11 @@ __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict
       else { lsum += fabsf(df); gf[d] = (df > 0.f ? inv_n : (df < 0.f ? -inv_n : 0.f)); }
     }
     float gp[BB_P];                                       // d(loss)/d(patch pixels)
-    if (GRAM) {                                           // G = F F^T / 27  ->  dF = (dG + dG^T) F / 27
+    if (GRAM == 2) {
+      float keep[54], ftmp[BB_P];
+      bb_st_forward(p, mats, ftmp, keep);                 // recomputed here: only one thread in 8 needs the intermediates
+      bb_st_backward(keep, mats, gf, gp);
+    } else if (GRAM == 1) {                               // G = F F^T / 27  ->  dF = (dG + dG^T) F / 27
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -177,19 +274,23 @@ __global__ __launch_bounds__(BB_NT) void bb_match_kernel(const float* __restrict
 }  // namespace
 
 SST_API int sst_bb_blocks(int B, int H, int W) { return B * (((H / 3) * (W / 3) + BB_Q - 1) / BB_Q); }
-SST_API int sst_bb_feature_dim(int gram) { return gram ? 9 : BB_P; }
+SST_API int sst_bb_feature_dim(int gram) { return gram == 1 ? 9 : BB_P; }
 
 // img [B,3,H,W] (H, W multiples of 3) -> rows [cand_off, cand_off + (H/3)(W/3)) of cand [B, ncand_total, D] and cnrm
-// [B, ncand_total]; D = sst_bb_feature_dim(gram): the raw 27-vector (BestBuddyLoss) or the 3x3 gram matrix (GramLoss).
+// [B, ncand_total]; D = sst_bb_feature_dim(gram): raw 27-vector (0, BestBuddyLoss), 3x3 gram matrix (1, GramLoss) or the
+// normalised 3x3-patch structure tensor (2, PatchwiseStructureTensorLoss; st_mats = device [Ax 81][Ay 81][K 81]).
 SST_API int sst_bb_patches(const float* img, float* cand, float* cnrm, int B, int H, int W, int ncand_total, int cand_off, int gram,
-                           void* stream) {
+                           const float* st_mats, void* stream) {
+  SST_REQUIRE(gram >= 0 && gram <= 2 && (gram != 2 || st_mats), "sst_bb_patches: feature mode 0..2, mode 2 needs st_mats");
   SST_REQUIRE(img && cand && cnrm && B > 0 && H >= 3 && W >= 3 && H % 3 == 0 && W % 3 == 0 &&
                   cand_off >= 0 && cand_off + (H / 3) * (W / 3) <= ncand_total, "sst_bb_patches: bad argument");
   const int total = B * (H / 3) * (W / 3);
-  if (gram)
-    bb_patches_kernel<1><<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(img, cand, cnrm, B, H, W, ncand_total, cand_off);
+  if (gram == 2)
+    bb_patches_kernel<2><<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(img, cand, cnrm, B, H, W, ncand_total, cand_off, st_mats);
+  else if (gram == 1)
+    bb_patches_kernel<1><<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(img, cand, cnrm, B, H, W, ncand_total, cand_off, nullptr);
   else
-    bb_patches_kernel<0><<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(img, cand, cnrm, B, H, W, ncand_total, cand_off);
+    bb_patches_kernel<0><<<(total + 255) / 256, 256, 0, sst_stream(stream)>>>(img, cand, cnrm, B, H, W, ncand_total, cand_off, nullptr);
   SST_LAUNCH_CHECK("bb_patches_kernel");
   return SST_OK;
 }
@@ -198,16 +299,20 @@ SST_API int sst_bb_patches(const float* img, float* cand, float* cnrm, int B, in
 // ind [B, nP] int32; dsr [B,3,H,W] = d(loss)/d(sr) for loss = sum(partials) (criterion mean over B*nP*D elements);
 // partials [sst_bb_blocks(B,H,W)].
 SST_API int sst_bb_match(const float* sr, const float* cand, const float* cnrm, int* ind, float* dsr, float* partials, int B, int H,
-                         int W, int ncand, float alpha, float beta, int criterion_l2, int gram, void* stream) {
+                         int W, int ncand, float alpha, float beta, int criterion_l2, int gram, const float* st_mats, void* stream) {
+  SST_REQUIRE(gram >= 0 && gram <= 2 && (gram != 2 || st_mats), "sst_bb_match: feature mode 0..2, mode 2 needs st_mats");
   SST_REQUIRE(sr && cand && cnrm && ind && dsr && partials && B > 0 && H >= 3 && W >= 3 && H % 3 == 0 && W % 3 == 0 &&
                   ncand >= (H / 3) * (W / 3), "sst_bb_match: bad argument");
   const float inv_n = 1.f / ((float)B * (H / 3) * (W / 3) * sst_bb_feature_dim(gram));
-  if (gram)
+  if (gram == 2)
+    bb_match_kernel<2><<<sst_bb_blocks(B, H, W), BB_NT, 0, sst_stream(stream)>>>(sr, cand, cnrm, ind, dsr, partials, B, H, W, ncand,
+                                                                                 alpha, beta, criterion_l2, inv_n, st_mats);
+  else if (gram == 1)
     bb_match_kernel<1><<<sst_bb_blocks(B, H, W), BB_NT, 0, sst_stream(stream)>>>(sr, cand, cnrm, ind, dsr, partials, B, H, W, ncand,
-                                                                                 alpha, beta, criterion_l2, inv_n);
+                                                                                 alpha, beta, criterion_l2, inv_n, nullptr);
   else
     bb_match_kernel<0><<<sst_bb_blocks(B, H, W), BB_NT, 0, sst_stream(stream)>>>(sr, cand, cnrm, ind, dsr, partials, B, H, W, ncand,
-                                                                                 alpha, beta, criterion_l2, inv_n);
+                                                                                 alpha, beta, criterion_l2, inv_n, nullptr);
   SST_LAUNCH_CHECK("bb_match_kernel");
   return SST_OK;
 }

@@ -85,8 +85,8 @@ SIGNATURES = {
     "sst_feat_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, P, P, c_float, c_int, c_int64, c_int, P]),
     "sst_bb_blocks": (c_int, [c_int, c_int, c_int]),
     "sst_bb_feature_dim": (c_int, [c_int]),
-    "sst_bb_patches": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "sst_bb_match": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P]),
+    "sst_bb_patches": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "sst_bb_match": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P]),
     "sst_weighted_sum": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, P, P, P]),
     "sst_wgrad_c3_supported": (c_int, [c_int, c_int]),
     "sst_wgrad_c3_slab_floats": (c_int64, [c_int, c_int, c_int, c_int]),

@@ -2,7 +2,7 @@
 
 StructureTensorLoss  <- reference loss.py:380-413 (+ utils.py:194-280), kernels csrc/st_loss.hip
 ContentLossVGG       <- reference loss.py:11-70, in vgg_loss.py (re-exported here)
-BestBuddyLoss / GramLoss <- reference loss.py:78-228, kernels csrc/bb_loss.hip
+BestBuddyLoss / GramLoss / PatchwiseStructureTensorLoss <- reference loss.py:78-228, 292-375, kernels csrc/bb_loss.hip
 ContentLossDiscriminator <- reference loss.py:231-289, in disc_loss.py (re-exported here)
 """
 from __future__ import annotations
@@ -201,7 +201,7 @@ def _torch_bicubic_taps(in_size: int, out_size: int, device):
 
 class _BestBuddyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gt, alpha, beta, l2, cache, gram=0):
+    def forward(ctx, x, gt, alpha, beta, l2, cache, gram=0, st_mats=None):
         if x.dtype != torch.float32 or x.shape != gt.shape or x.dim() != 4 or x.shape[1] != 3:
             raise _abi.HipPathError("BestBuddyLoss / GramLoss: fp32 [B,3,H,W] pairs")
         B, _, H, W = x.shape
@@ -218,21 +218,21 @@ class _BestBuddyFn(torch.autograd.Function):
         cand = torch.empty(B, ncand, lib.sst_bb_feature_dim(int(gram)), device=dev, dtype=torch.float32)
         cnrm = torch.empty(B, ncand, device=dev, dtype=torch.float32)
         st = _abi.stream_ptr()
-        _abi.check(lib.sst_bb_patches(_abi.ptr(gt), _abi.ptr(cand), _abi.ptr(cnrm), B, H, W, ncand, 0, int(gram), st), "sst_bb_patches")
+        _abi.check(lib.sst_bb_patches(_abi.ptr(gt), _abi.ptr(cand), _abi.ptr(cnrm), B, H, W, ncand, 0, int(gram), _abi.ptr(st_mats), st), "sst_bb_patches")
         off = nps[0]
         for k, s in enumerate((2, 4)):                       # GT at 1/2 and 1/4 resolution (torch bicubic), then its patches
             (wy, iy), (wx, ix) = cache["taps"][k]
             small = torch.empty(B, 3, H // s, W // s, device=dev, dtype=torch.float32)
             _abi.check(lib.sst_bicubic(_abi.ptr(gt), _abi.ptr(small), _abi.ptr(wy), _abi.ptr(iy), _abi.ptr(wx), _abi.ptr(ix), B * 3, H, W,
                                        H // s, W // s, 4, 4, 0, st), "sst_bicubic")
-            _abi.check(lib.sst_bb_patches(_abi.ptr(small), _abi.ptr(cand), _abi.ptr(cnrm), B, H // s, W // s, ncand, off, int(gram), st),
-                       "sst_bb_patches")
+            _abi.check(lib.sst_bb_patches(_abi.ptr(small), _abi.ptr(cand), _abi.ptr(cnrm), B, H // s, W // s, ncand, off, int(gram),
+                                          _abi.ptr(st_mats), st), "sst_bb_patches")
             off += nps[k + 1]
         ind = torch.empty(B, nps[0], device=dev, dtype=torch.int32)
         dsr = torch.empty_like(x)
         partials = torch.empty(lib.sst_bb_blocks(B, H, W), device=dev, dtype=torch.float32)
         _abi.check(lib.sst_bb_match(_abi.ptr(x), _abi.ptr(cand), _abi.ptr(cnrm), _abi.ptr(ind), _abi.ptr(dsr), _abi.ptr(partials), B, H, W,
-                                    ncand, float(alpha), float(beta), int(l2), int(gram), st), "sst_bb_match")
+                                    ncand, float(alpha), float(beta), int(l2), int(gram), _abi.ptr(st_mats), st), "sst_bb_match")
         ctx.save_for_backward(dsr)
         ctx.mark_non_differentiable(ind)
         return partials.sum(), ind
@@ -240,7 +240,7 @@ class _BestBuddyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _grad_ind):
         (dsr,) = ctx.saved_tensors
-        return dsr * grad_out, None, None, None, None, None, None
+        return dsr * grad_out, None, None, None, None, None, None, None
 
 
 class BestBuddyLoss(nn.Module):
@@ -282,6 +282,59 @@ class GramLoss(nn.Module):
 
     def forward(self, x, gt):
         loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache, 1)
+        self.last_index = ind
+        return loss
+
+
+def _patch_st_matrices(sigma: float, rho: float, device):
+    """The three 9x9 linear maps of utils.py:212-233 on a zero-padded 3x3 image, row-major [out pixel][in pixel]:
+    Ix = Ax g (derivative taps along H, Gaussian along W), Iy = Ay g, J = K (product)  -> device tensor [3*81]."""
+    def taps(s, also_dg=False):                         # utils.py:194-208 (fp32 taps from an int64 arange)
+        radius = max(int(4 * s + 0.5), 1)
+        xs = torch.arange(-radius, radius + 1)
+        s2 = s * s + 1e-12
+        phi = torch.exp(-0.5 / s2 * xs ** 2)
+        phi = phi / phi.sum()
+        return (phi, phi * -xs / s2, radius) if also_dg else (phi, radius)
+
+    g, dg, r1 = taps(sigma, True)
+    k, r2 = taps(rho)
+
+    def mat(kv, kh, r):                                  # out (y,x) <- in (y',x'):  kv[y'-y+r] * kh[x'-x+r]
+        m = torch.zeros(9, 9)
+        for y in range(3):
+            for x in range(3):
+                for yy in range(3):
+                    for xx in range(3):
+                        a, b = yy - y + r, xx - x + r
+                        if 0 <= a <= 2 * r and 0 <= b <= 2 * r:
+                            m[y * 3 + x, yy * 3 + xx] = kv[a] * kh[b]
+        return m
+
+    return torch.cat([mat(dg, g, r1).reshape(-1), mat(g, dg, r1).reshape(-1), mat(k, k, r2).reshape(-1)]).to(torch.float32).to(device)
+
+
+class PatchwiseStructureTensorLoss(nn.Module):
+    """Reference loss.py:292-375 (best-buddy matching on the normalised structure tensor of every 3x3 patch) on the HIP path.
+    Same constructor; supported: ksize 3, dist_norm 'l2', criterion 'l1' or 'l2' / 'mse'."""
+
+    def __init__(self, sigma: float = 0.5, rho: float = 2, alpha: float = 1.0, beta: float = 1.0, ksize: int = 3, dist_norm: str = "l2",
+                 criterion: str = "l1"):
+        super().__init__()
+        if (ksize, dist_norm) != (3, "l2"):
+            raise NotImplementedError("PatchwiseStructureTensorLoss on the HIP path: ksize=3, dist_norm='l2' only")
+        if criterion not in ("l1", "l2", "mse"):
+            raise NotImplementedError("%s criterion has not been supported." % criterion)
+        self.sigma, self.rho, self.alpha, self.beta, self.ksize, self.dist_norm = sigma, rho, alpha, beta, ksize, dist_norm
+        self.l2 = criterion != "l1"
+        self._cache = {}
+        self._mats = None
+        self.last_index = None
+
+    def forward(self, x, gt):
+        if self._mats is None or self._mats.device != x.device:
+            self._mats = _patch_st_matrices(float(self.sigma), float(self.rho), x.device)
+        loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache, 2, self._mats)
         self.last_index = ind
         return loss
 

@@ -55,6 +55,22 @@ def main():
         arrs[f"{name}/gram/ind"] = gtop.indices[..., 0].numpy().astype(np.int32)
         arrs[f"{name}/gram/margin"] = (gtop.values[..., 1] - gtop.values[..., 0]).numpy()
         arrs[f"{name}/gram/p1"] = q1.numpy()
+        # PatchwiseStructureTensorLoss (loss.py:292-375) on the same pair
+        for crit in ("l1", "l2"):
+            pm = rloss.PatchwiseStructureTensorLoss(criterion=crit)
+            pl = pm(x, gt)
+            (pgx,) = torch.autograd.grad(pl, x)
+            arrs[f"{name}/pst/{crit}/loss"] = pl.detach().numpy()
+            arrs[f"{name}/pst/{crit}/grad"] = pgx.numpy()
+        with torch.no_grad():
+            pm = rloss.PatchwiseStructureTensorLoss()
+            s1, s2 = pm.compute_patches(x), pm.compute_patches(gt)
+            scat = torch.cat([s2, pm.compute_patches(gt2), pm.compute_patches(gt4)], 1)
+            ss = rutils.batch_pairwise_distance(s1, scat, "l2") + rutils.batch_pairwise_distance(s2, scat, "l2")
+            stop = torch.topk(ss, 2, dim=2, largest=False)
+        arrs[f"{name}/pst/ind"] = stop.indices[..., 0].numpy().astype(np.int32)
+        arrs[f"{name}/pst/margin"] = (stop.values[..., 1] - stop.values[..., 0]).numpy()
+        arrs[f"{name}/pst/p1"] = s1.numpy()
     save("bestbuddy", **arrs)
 
 
