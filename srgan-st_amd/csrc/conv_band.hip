@@ -33,7 +33,9 @@ namespace {
 
 constexpr int PSTR = 20;   // LDS floats per patch pixel of one wave's 16-channel slice (16 + 4 pad: conflict-free b128 reads)
 
-template <int NB>
+// FUSED: the two-tensor input forms (BatchNorm-backward apply, residual sum) and the backward epilogue sums are compiled in;
+// the plain forward instance carries neither their registers nor their code.
+template <int NB, bool FUSED>
 __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(Conv3Args a, int R, int nbands, BandAcc ba) {   // NB = 3: keep 3 workgroups per CU (<= 168 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sstat[4][3][16];
@@ -129,8 +131,9 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
       if (ba.in_target == 0) { sc = s4; sh = t4; have_aff = true; }
       else { kB = s4; kC = t4; have_k = true; }
     };
-    if (ba.in_acc) affine_from_acc();
-    if (ba.bw_in_acc) {
+    if (ba.in_acc) affine_from_acc();     // before the patch loads (reducing it after issuing them was measured: the compiler
+                                          // spills in every variant tried, 3x slower)
+    if (FUSED && ba.bw_in_acc) {
       // BatchNorm-backward coefficients of the input from the producer's accumulators [nrep][64][4] (same lane mapping)
       double S0 = 0.0, S1 = 0.0, S2 = 0.0;
       const float mu = ba.bw_mean[wave * 16 + (lane & 15)], rs = ba.bw_rstd[wave * 16 + (lane & 15)],
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
       have_k = true;
     }
     const float* xb = a.x + (size_t)b * a.H * W * 64 + c;
-    const float* x2b = a.in2 ? a.in2 + (size_t)b * a.H * W * 64 + c : nullptr;
+    const float* x2b = (FUSED && a.in2) ? a.in2 + (size_t)b * a.H * W * 64 + c : nullptr;
     float* sob = (a.side_out && g == 0) ? a.side_out + (size_t)b * a.H * W * 64 + c : nullptr;
     // patch pixel p = it*16 + lane/4  ->  (py, px), advanced incrementally (no per-iteration division)
     int p = lane >> 2;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     }
   }
 
-  if (a.epi_partial || ba.bw_st_acc) {
+  if (FUSED && (a.epi_partial || ba.bw_st_acc)) {
     // backward partials of the stored g against epi_y (see Conv3Args): sums of (gz, gz*y, g*min(z,0)) over the band
     const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
     f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
@@ -483,17 +486,23 @@ int sst_launch_conv_band(const Conv3Args& a, int R, hipStream_t st, const BandAc
   const size_t lds = band_lds_bytes(R, a.W, NB);
   static bool big_lds_enabled = false;     // > 64 KB of dynamic LDS needs the opt-in (gfx950 has 160 KB per CU)
   if (!big_lds_enabled) {
-    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band_kernel<9>),
+    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band_kernel<3, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band_kernel<3>),
+    if (e0 != hipSuccess) return sst_set_error(SST_ERR_HIP, "conv_band: cannot raise the LDS limit");
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band_kernel<9, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_band_kernel<3, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e1 != hipSuccess || e2 != hipSuccess) return sst_set_error(SST_ERR_HIP, "conv_band: cannot raise the LDS limit");
     big_lds_enabled = true;
   }
   if (NB == 9)
-    conv_band_kernel<9><<<grid, CONV_NT, lds, st>>>(a, R, nbands, ba);
+    conv_band_kernel<9, true><<<grid, CONV_NT, lds, st>>>(a, R, nbands, ba);
   else if (NB == 3)
-    conv_band_kernel<3><<<grid, CONV_NT, lds, st>>>(a, R, nbands, ba);
+    if (a.in2 || a.epi_partial || ba.bw_in_acc || ba.bw_st_acc)
+      conv_band_kernel<3, true><<<grid, CONV_NT, lds, st>>>(a, R, nbands, ba);
+    else
+      conv_band_kernel<3, false><<<grid, CONV_NT, lds, st>>>(a, R, nbands, ba);
   else
     return sst_set_error(SST_ERR_UNSUPPORTED, "conv_band: NB=%d not built", NB);
   SST_LAUNCH_CHECK("conv_band_kernel");
