@@ -129,3 +129,33 @@ def test_bucket_slices():
     sl = bucket_slices([10, 1, 1, 30, 2], 2)
     assert sl[0][0] == 0 and sl[-1][1] == 5 and all(a < b for a, b in sl)
     assert [i for a, b in sl for i in range(a, b)] == list(range(5))
+
+
+def test_torch_bicubic_tap_tables_match_interpolate():
+    """Host-built tap tables for the 1/2 and 1/4 GT scales of the best-buddy losses (srganst.loss._torch_bicubic_taps) against
+    F.interpolate(mode='bicubic', align_corners=False) itself."""
+    import torch.nn.functional as F
+    from srganst.loss import _torch_bicubic_taps
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 3, 48, 36, generator=g)
+    for s in (2, 4):
+        (wy, iy), (wx, ix) = _torch_bicubic_taps(48, 48 // s, "cpu"), _torch_bicubic_taps(36, 36 // s, "cpu")
+        v = (x[:, :, iy.long(), :] * wy.view(1, 1, -1, 4, 1)).sum(3)                  # vertical pass  [B,C,oh,W]
+        out = (v[:, :, :, ix.long()] * wx.view(1, 1, 1, -1, 4)).sum(4)               # horizontal pass
+        ref = F.interpolate(x, scale_factor=1.0 / s, mode="bicubic", align_corners=False)
+        assert out.shape == ref.shape and torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_patch_structure_tensor_matrices_match_oracle():
+    """The three 9x9 maps that srganst.loss._patch_st_matrices builds for PatchwiseStructureTensorLoss reproduce the oracle's
+    structure tensor on zero-padded 3x3 patches."""
+    from oracle import st as ost
+    from srganst.loss import _patch_st_matrices
+    g = torch.Generator().manual_seed(32)
+    gray = torch.rand(50, 1, 3, 3, generator=g)
+    m = _patch_st_matrices(0.5, 2.0, "cpu").view(3, 9, 9).double()
+    v = gray.view(50, 9).double()
+    ix, iy = v @ m[0].T, v @ m[1].T
+    J = torch.stack([(ix * ix) @ m[2].T, (iy * iy) @ m[2].T, (ix * iy) @ m[2].T], dim=1).view(50, 3, 3, 3)
+    ref = ost.structure_tensor(gray.double(), 0.5, 2.0)
+    assert float((J - ref).abs().max() / ref.abs().max()) < 1e-6
