@@ -177,22 +177,6 @@ int sst_bwd_reduce_blocks(int64_t R, int C);
 int sst_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale,
                    const float* shift, const float* slope, float slope_const, int act, float* partial,
                    int64_t R, int C, void* stream);
-/* reduce + finalize in one launch (last-arriving workgroup finalizes); counter: one zeroed word, left zero */
-int sst_bwd_reduce_finalize(const float* g, const float* g2, const float* y, const float* scale,
-                            const float* shift, const float* slope, float slope_const, int act,
-                            float* partial, int64_t R, int C, unsigned* counter, float n, const float* mean,
-                            const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
-                            float* cB, float* cC, float* dslope, int accumulate, void* stream);
-/* few-workgroup reduce + apply with the finalize folded into every workgroup's prologue (no hand-off at all) */
-int sst_bwd_reduce_blocks_small(int64_t R, int C);
-int sst_bwd_reduce_small(const float* g, const float* g2, const float* y, const float* scale,
-                         const float* shift, const float* slope, float slope_const, int act, float* partial,
-                         int64_t R, int C, void* stream);
-int sst_bwd_apply_fused(const float* g, const float* g2, const float* y, const float* scale,
-                        const float* shift, const float* slope, float slope_const, int act,
-                        const float* partial, int nblk, float n, const float* mean, const float* rstd,
-                        const float* gamma, float* dgamma, float* dbeta, float* dslope, int accumulate,
-                        float* dy, int64_t R, int C, int unshuffle_H, int unshuffle_W, void* stream);
 int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean,
                      const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
                      float* cB, float* cC, float* dslope, int accumulate, void* stream);
@@ -211,7 +195,6 @@ int sst_bwd_apply(const float* g, const float* g2, const float* y, const float* 
                   const float* cB, const float* cC, float* dy, int64_t R, int C, int unshuffle_H,
                   int unshuffle_W, void* stream);
 int sst_add(const float* a, const float* b, float* out, int64_t n, void* stream);
-int sst_slab_reduce(const float* slabs, float* out, int nslab, int64_t n, int accumulate, void* stream);
 
 /* ---- layout + criterions ------------------------------------------------------------------------
  * sst_transpose: NCHW <-> NHWC (model.py:138-152 keeps an NCHW surface).  sst_clamp_bwd: backward of

@@ -153,80 +153,12 @@ __global__ __launch_bounds__(NT) void bn_residual_kernel(const float* __restrict
   }
 }
 
-// Finalize of the backward reductions, executed by ONE workgroup of FT threads (either the separate
-// bwd_finalize_kernel or the last-arriving workgroup of bwd_reduce_kernel).  If mean != null (BatchNorm):
-// writes dgamma, dbeta and the coefficients of   dy = cA[c]*gz + cB[c]*y + cC[c]   else (bias-only layer)
-// dbeta = sum gz.  dslope (scalar) = sum_c partial[2] when dslope != null.  L lanes per channel split the
-// nblk partials; lane 0 of each channel combines them in fixed order.
+// Arguments of the backward finalize (bwd_finalize2_kernel below).
 struct FinArgs {
   const float* mean; const float* rstd; const float* gamma;
   float* dgamma; float* dbeta; float* cA; float* cB; float* cC; float* dslope;
   float n; int accumulate;
 };
-
-template <int FT, bool AGENT_LOADS>
-__device__ __forceinline__ void bwd_finalize_body(const float* __restrict__ partial, int nblk, int C, const FinArgs& f,
-                                                  float* sm /* [3][FT] */, float* red /* [FT/64] */,
-                                                  bool write_grads = true) {
-  float al = 0.f;
-  const int L = C >= FT ? 1 : FT / C;
-  for (int cbase = 0; cbase < C; cbase += FT / L) {
-    const int c = cbase + (int)threadIdx.x / L, q = threadIdx.x % L;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-      for (int b = q; b < nblk; b += L) {
-        const float* p = partial + (size_t)b * 3 * C + c;
-        if (AGENT_LOADS) {
-          s0 += load_agent(p);
-          s1 += load_agent(p + C);
-          s2 += load_agent(p + 2 * C);
-        } else {
-          s0 += p[0];
-          s1 += p[C];
-          s2 += p[2 * C];
-        }
-      }
-    }
-    __syncthreads();
-    sm[threadIdx.x] = s0;
-    sm[FT + threadIdx.x] = s1;
-    sm[2 * FT + threadIdx.x] = s2;
-    __syncthreads();
-    if (c < C && q == 0) {
-      s0 = s1 = s2 = 0.f;
-      for (int i = 0; i < L; ++i) {
-        s0 += sm[threadIdx.x + i];
-        s1 += sm[FT + threadIdx.x + i];
-        s2 += sm[2 * FT + threadIdx.x + i];
-      }
-      al += s2;
-      if (f.mean) {
-        const float mu = f.mean[c], rs = f.rstd[c], ga = f.gamma[c];
-        const float sgh = rs * (s1 - mu * s0);   // sum gz * yhat
-        const float m1 = s0 / f.n, m2 = sgh / f.n;
-        if (write_grads) {
-          if (f.accumulate) {
-            f.dgamma[c] += sgh;
-            f.dbeta[c] += s0;
-          } else {
-            f.dgamma[c] = sgh;
-            f.dbeta[c] = s0;
-          }
-        }
-        const float a = ga * rs;
-        f.cA[c] = a;
-        f.cB[c] = -a * rs * m2;
-        f.cC[c] = -a * m1 + a * rs * mu * m2;
-      } else if (f.dbeta && write_grads) {
-        if (f.accumulate) f.dbeta[c] += s0; else f.dbeta[c] = s0;
-      }
-    }
-  }
-  al = block_sum<FT>(al, red);
-  if (f.dslope && write_grads && threadIdx.x == 0) {
-    if (f.accumulate) f.dslope[0] += al; else f.dslope[0] = al;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Backward reductions over rows.  With z = y*scale+shift (or z = y when scale == null) and
@@ -237,9 +169,8 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ slope_p,
                                                         float slope_c, int act, float* __restrict__ partial, int64_t R,
-                                                        int C, int rows_per_block, unsigned* __restrict__ counter, FinArgs fin) {
-  extern __shared__ float sm[];  // [rowlanes][3][C]   (>= 3*NT + NT/64 floats when the finalize is fused)
-  __shared__ unsigned s_last;
+                                                        int C, int rows_per_block) {
+  extern __shared__ float sm[];  // [rowlanes][3][C]
   const int c4n = C >> 2;
   const int rowlanes = NT / c4n;
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
@@ -286,20 +217,6 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
     float t = 0.f;
     for (int q = 0; q < rowlanes; ++q) t += sm[(size_t)q * 3 * C + i];
     partial[(size_t)blockIdx.x * 3 * C + i] = t;
-  }
-  if (counter) {
-    // fused finalize: every storing wave drains its stores, the workgroup meets, one lane releases + takes a
-    // ticket (agent scope); the last arriver acquires and reduces all partials in fixed order (cdna guide G16).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (publish_and_ticket(counter) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (s_last) {
-      if (threadIdx.x == 0) acquire_after_ticket();
-      __syncthreads();
-      bwd_finalize_body<NT, false>(partial, gridDim.x, C, fin, sm, sm + 3 * NT);   // plain loads: the acquire above + barrier cover the CU's L1
-      if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 
@@ -388,13 +305,6 @@ __global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restr
   }
 }
 
-constexpr int FT = 1024;   // threads of the stand-alone finalize kernel
-__global__ __launch_bounds__(FT) void bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f) {
-  __shared__ float sm[3 * FT];
-  __shared__ float red[FT / 64];
-  bwd_finalize_body<FT, false>(partial, nblk, C, f, sm, red);
-}
-
 // dy = cA*gz + cB*y + cC  (BatchNorm input gradient), or dy = gz when cA == null (activation only).
 __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ g2,
                                                        const float* __restrict__ y, const float* __restrict__ scale,
@@ -435,71 +345,11 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
   }
 }
 
-// bwd_apply with the finalize folded in: each workgroup reduces the (few) per-workgroup partials of bwd_reduce
-// into LDS coefficients itself - no separate finalize launch, no inter-workgroup hand-off.  Workgroup 0 also
-// writes the parameter gradients (dgamma/dbeta/dslope).  C <= 512.
-constexpr int AF_MAXC = 512;
-__global__ __launch_bounds__(NT) void bwd_apply_fused_kernel(const float* __restrict__ g, const float* __restrict__ g2,
-                                                             const float* __restrict__ y, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, const float* __restrict__ slope_p,
-                                                             float slope_c, int act, const float* __restrict__ partial,
-                                                             int nblk, FinArgs fin, float* __restrict__ dy, int64_t R, int C,
-                                                             int uH, int uW) {
-  __shared__ float sm[3 * NT + NT / 64];
-  __shared__ float sco[3 * AF_MAXC];
-  const bool bn = fin.mean != nullptr;
-  FinArgs f = fin;
-  f.cA = sco; f.cB = sco + AF_MAXC; f.cC = sco + 2 * AF_MAXC;
-  if (bn || blockIdx.x == 0) bwd_finalize_body<NT, false>(partial, nblk, C, f, sm, sm + 3 * NT, blockIdx.x == 0);
-  __syncthreads();
-  const int c4n = C >> 2;
-  const int64_t total = R * c4n;
-  const float slope = slope_p ? slope_p[0] : slope_c;
-  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
-    const int c = (int)(i % c4n) * 4;
-    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
-    if (g2) gv += reinterpret_cast<const f32x4*>(g2)[i];
-    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float gz = gv[j];
-      if (act) {
-        const float z = scale ? fmaf(yv[j], scale[c + j], shift[c + j]) : yv[j];
-        gz = z > 0.f ? gz : gz * slope;
-      }
-      o[j] = bn ? fmaf(sco[c + j], gz, fmaf(sco[AF_MAXC + c + j], yv[j], sco[2 * AF_MAXC + c + j])) : gz;
-    }
-    if (uW == 0) {
-      reinterpret_cast<f32x4*>(dy)[i] = o;
-    } else {
-      const int64_t r = i / c4n;
-      const int X = (int)(r % uW);
-      const int64_t t = r / uW;
-      const int Y = (int)(t % uH);
-      const int64_t b = t / uH;
-      float* d = dy + (((b * (uH >> 1) + (Y >> 1)) * (uW >> 1) + (X >> 1)) * (int64_t)(4 * C)) + 2 * (Y & 1) + (X & 1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[4 * (c + j)] = o[j];
-    }
-  }
-}
-
 // out[i] = a[i] + b[i]
 __global__ __launch_bounds__(NT) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ out, int64_t n4) {
   for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT)
     reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
-}
-
-// Sum of nslab consecutive slabs of n floats:  out[i] (+)= sum_s slabs[s*n + i]    (split-K wgrad reduction)
-__global__ __launch_bounds__(NT) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int nslab,
-                                                         int64_t n, int accumulate) {
-  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-    float t = 0.f;
-    for (int s = 0; s < nslab; ++s) t += slabs[(size_t)s * n + i];
-    out[i] = accumulate ? out[i] + t : t;
-  }
 }
 
 inline int grid_for(int64_t work_items) {
@@ -548,12 +398,6 @@ SST_API int sst_bn_residual(const float* y, const float* scale, const float* shi
   return SST_OK;
 }
 
-SST_API int sst_bwd_reduce_blocks_small(int64_t R, int C) {
-  int64_t nb = (R + 255) / 256;
-  if (nb > 32) nb = 32;
-  return (int)(nb < 1 ? 1 : nb);
-}
-
 SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
   // ~8 float4 per thread, at most 128 workgroups (the finalize kernel walks nblk partials per channel)
   int64_t nb = (R * (C / 4) + 256 * 8 - 1) / (256 * 8);
@@ -564,18 +408,15 @@ SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
 
 static int launch_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
                              const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
-                             unsigned* counter, const FinArgs& fin, void* stream, int nblk_override = 0) {
+                             void* stream) {
   SST_REQUIRE(g && y && partial && R > 0 && C >= 4 && (C & 3) == 0 && C <= 1024, "sst_bwd_reduce: bad argument (C=%d)", C);
   SST_REQUIRE(NT % (C / 4) == 0 || C / 4 > NT, "sst_bwd_reduce: C/4 must divide %d", NT);
   SST_REQUIRE(C / 4 <= NT, "sst_bwd_reduce: C too large");
-  const int nblk = nblk_override ? nblk_override : sst_bwd_reduce_blocks(R, C);
+  const int nblk = sst_bwd_reduce_blocks(R, C);
   const int rpb = (int)((R + nblk - 1) / nblk);
   const int rowlanes = NT / (C / 4);
-  size_t smem = (size_t)rowlanes * 3 * C * sizeof(float);
-  const size_t fin_smem = (size_t)(3 * NT + NT / 64) * sizeof(float);
-  if (counter && smem < fin_smem) smem = fin_smem;
-  bwd_reduce_kernel<<<nblk, NT, smem, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C,
-                                                             rpb, counter, fin);
+  const size_t smem = (size_t)rowlanes * 3 * C * sizeof(float);
+  bwd_reduce_kernel<<<nblk, NT, smem, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, rpb);
   SST_LAUNCH_CHECK("bwd_reduce_kernel");
   return SST_OK;
 }
@@ -583,51 +424,7 @@ static int launch_bwd_reduce(const float* g, const float* g2, const float* y, co
 SST_API int sst_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
                            const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
                            void* stream) {
-  FinArgs fin = {};
-  return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, nullptr, fin, stream);
-}
-
-// bwd_reduce + bwd_finalize in one launch (the last-arriving workgroup finalizes).  counter: one zeroed word,
-// left zero again by the kernel.
-SST_API int sst_bwd_reduce_finalize(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
-                                    const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
-                                    unsigned* counter, float n, const float* mean, const float* rstd, const float* gamma,
-                                    float* dgamma, float* dbeta, float* cA, float* cB, float* cC, float* dslope,
-                                    int accumulate, void* stream) {
-  SST_REQUIRE(counter, "sst_bwd_reduce_finalize: counter");
-  SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_reduce_finalize: BN mode needs all BN pointers");
-  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
-  return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, counter, fin, stream);
-}
-
-// bwd_reduce with few workgroups (sst_bwd_reduce_blocks_small) + bwd_apply with the finalize folded in.
-SST_API int sst_bwd_reduce_small(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
-                                 const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
-                                 void* stream) {
-  FinArgs fin = {};
-  return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, nullptr, fin, stream,
-                           sst_bwd_reduce_blocks_small(R, C));
-}
-
-SST_API int sst_bwd_apply_fused(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
-                                const float* slope, float slope_const, int act, const float* partial, int nblk, float n,
-                                const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta,
-                                float* dslope, int accumulate, float* dy, int64_t R, int C, int unshuffle_H, int unshuffle_W,
-                                void* stream) {
-  SST_REQUIRE(g && y && dy && partial && nblk > 0 && R > 0 && C > 0 && (C & 3) == 0 && C <= AF_MAXC,
-              "sst_bwd_apply_fused: bad argument (C=%d)", C);
-  SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta), "sst_bwd_apply_fused: BN mode needs rstd/gamma/dgamma/dbeta");
-  SST_REQUIRE(unshuffle_W == 0 || ((unshuffle_H & 1) == 0 && (unshuffle_W & 1) == 0 &&
-                                   R % ((int64_t)unshuffle_H * unshuffle_W) == 0),
-              "sst_bwd_apply_fused: bad unshuffle geometry");
-  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, nullptr, nullptr, nullptr, dslope, n, accumulate};
-  int64_t blocks = (R * (C / 4) + 4 * NT - 1) / (4 * NT);     // ~4 float4 per thread: amortises the coefficient prologue
-  if (blocks > 1024) blocks = 1024;
-  if (blocks < 1) blocks = 1;
-  bwd_apply_fused_kernel<<<(int)blocks, NT, 0, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial,
-                                                                    nblk, fin, dy, R, C, unshuffle_H, unshuffle_W);
-  SST_LAUNCH_CHECK("bwd_apply_fused_kernel");
-  return SST_OK;
+  return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, stream);
 }
 
 SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean, const float* rstd,
@@ -787,9 +584,3 @@ SST_API int sst_add(const float* a, const float* b, float* out, int64_t n, void*
   return SST_OK;
 }
 
-SST_API int sst_slab_reduce(const float* slabs, float* out, int nslab, int64_t n, int accumulate, void* stream) {
-  SST_REQUIRE(slabs && out && nslab > 0 && n > 0, "sst_slab_reduce: bad argument");
-  slab_reduce_kernel<<<grid_for(n), NT, 0, sst_stream(stream)>>>(slabs, out, nslab, n, accumulate);
-  SST_LAUNCH_CHECK("slab_reduce_kernel");
-  return SST_OK;
-}

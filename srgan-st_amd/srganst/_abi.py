@@ -25,8 +25,6 @@ SIGNATURES = {
     "sst_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
     "sst_conv_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "sst_conv_pack_multi": (c_int, [P, c_int, c_int, P]),
-    "sst_bwd_reduce_finalize": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P, c_float, P, P, P, P, P, P, P, P,
-                                        P, c_int, P]),
     "sst_conv_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_wgrad_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_debug_big_tile_launches": (ctypes.c_long, []),
@@ -59,17 +57,12 @@ SIGNATURES = {
     "sst_bn_residual": (c_int, [P, P, P, P, P, P, c_int64, c_int, P]),
     "sst_bwd_reduce_blocks": (c_int, [c_int64, c_int]),
     "sst_bwd_reduce": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P]),
-    "sst_bwd_reduce_blocks_small": (c_int, [c_int64, c_int]),
-    "sst_bwd_reduce_small": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P]),
-    "sst_bwd_apply_fused": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int, c_float, P, P, P, P, P, P, c_int, P, c_int64,
-                                    c_int, c_int, c_int, P]),
     "sst_bwd_finalize": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P]),
     "sst_bwd_finalize_wide": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P, P, P]),
     "sst_act_bwd_partial_blocks": (c_int, [c_int64]),
     "sst_act_bwd_partial": (c_int, [P, P, P, P, c_float, P, P, c_int64, c_int, c_int, c_int, P]),
     "sst_bwd_apply": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     "sst_add": (c_int, [P, P, P, c_int64, P]),
-    "sst_slab_reduce": (c_int, [P, P, c_int, c_int64, c_int, P]),
     "sst_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_transpose_affine": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "sst_maxpool_relu_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

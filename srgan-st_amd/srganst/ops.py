@@ -548,23 +548,6 @@ def _next_counter(device):
     return st[0].data_ptr() + 4 * i
 
 
-def bwd_reduce_finalize(g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
-                        gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False):
-    """bwd_reduce + bwd_finalize in one launch.  Returns (cA, cB, cC) in BN mode (mean given), else (None,)*3."""
-    C = y.shape[-1]
-    R = y.numel() // C
-    nblk = _abi.lib().sst_bwd_reduce_blocks(R, C)
-    partial = _f32(nblk, 3, C, like=y)
-    cA = cB = cC = None
-    if mean is not None:
-        cA, cB, cC = (_f32(C, like=y) for _ in range(3))
-    check(_abi.lib().sst_bwd_reduce_finalize(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const),
-                                             int(act), ptr(partial), R, C, _next_counter(y.device), float(n), ptr(mean), ptr(rstd),
-                                             ptr(gamma), ptr(dgamma), ptr(dbeta), ptr(cA), ptr(cB), ptr(cC), ptr(dslope),
-                                             int(accumulate), stream_ptr()), "sst_bwd_reduce_finalize")
-    return cA, cB, cC
-
-
 def flatten_bn_counters(module):
     """Make every BatchNorm's num_batches_tracked a view of one int64 tensor so a train-mode forward bumps them
     with a single add (33 launches -> 1 for the generator).  Idempotent; re-done if the buffers were moved."""
@@ -663,27 +646,6 @@ def bwd_reduce_apply(g, y, n, g2=None, scale=None, shift=None, slope=None, slope
     cA, cB, cC = bwd_finalize(part, n, mean, rstd, gamma, dgamma, dbeta, dslope, accumulate)
     return bwd_apply(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act, cA=cA, cB=cB, cC=cC,
                      unshuffle=unshuffle)
-
-
-def _bwd_reduce_apply_fused(g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
-                            gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False):
-    """Two-launch variant (finalize folded into every apply workgroup); slower once C * nblk grows - kept for A/B."""
-    C = y.shape[-1]
-    R = y.numel() // C
-    nblk = _abi.lib().sst_bwd_reduce_blocks_small(R, C)
-    partial = _f32(nblk, 3, C, like=y)
-    check(_abi.lib().sst_bwd_reduce_small(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
-                                          ptr(partial), R, C, stream_ptr()), "sst_bwd_reduce_small")
-    uh = uw = 0
-    if unshuffle:
-        B, uh, uw, _ = y.shape
-        dy = _f32(B, uh // 2, uw // 2, 4 * C, like=y)
-    else:
-        dy = torch.empty_like(y)
-    check(_abi.lib().sst_bwd_apply_fused(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
-                                         ptr(partial), nblk, float(n), ptr(mean), ptr(rstd), ptr(gamma), ptr(dgamma), ptr(dbeta),
-                                         ptr(dslope), int(accumulate), ptr(dy), R, C, uh, uw, stream_ptr()), "sst_bwd_apply_fused")
-    return dy
 
 
 def transpose_affine(x, to_nchw: bool, scale, shift=None):
