@@ -28,6 +28,17 @@ def make_adam(module, lr, betas, eps, weight_decay, capturable):
     return FlatAdam(module, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)
 
 
+_ONES = {}
+
+
+def _one(like):
+    # persistent seed of backward(): autograd would otherwise launch a ones_like fill every step
+    o = _ONES.get(like.device)
+    if o is None:
+        o = _ONES[like.device] = torch.ones((), device=like.device, dtype=torch.float32)
+    return o
+
+
 def _criterion_total(sr, gt, criterions, weights, adversarial=None):
     """sum_name weight * criterion(sr, gt) as in the reference loops (train.py:129-140, warmup.py:79-86); the values come
     back per name (already weighted, detached).  HIP-path pixel / structure-tensor terms share one autograd node
@@ -120,7 +131,7 @@ class WarmupEngine:
         self.opt.zero_grad(set_to_none=True)
         sr = self.G(self.lr)
         total, vals = _criterion_total(sr, self.gt, self.criterions, self.weights)
-        total.backward()
+        total.backward(_one(total))
         self.sr = sr.detach()
         self.loss_values = vals
         return vals
@@ -191,7 +202,7 @@ class TrainEngine:
         sr = self.G(self.lr)
         total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
                                        adversarial=lambda crit: crit(self.D(sr), self.real))
-        total.backward()
+        total.backward(_one(total))
         self.sr = sr.detach()
         self.loss_values = vals
         return vals
@@ -208,12 +219,12 @@ class TrainEngine:
         self.d_opt.zero_grad(set_to_none=True)
         pred_gt = self.D(self.gt)
         loss_real = self.adv(pred_gt, self.real)
-        pred_sr = self.D(self.sr.detach().clone())
+        pred_sr = self.D(self.sr)                            # train.py:158 detaches + clones; self.sr is detached and D only reads it
         loss_fake = self.adv(pred_sr, self.fake)
         d_loss = loss_real + loss_fake
         self.D.__dict__["_grad_accum"] = {"flat": None}      # both backward passes write ONE flat gradient buffer (disc_graph.backward)
         try:
-            d_loss.backward()
+            d_loss.backward(_one(d_loss))
         finally:
             self.D.__dict__.pop("_grad_accum", None)
         self.d_loss, self.pred_gt, self.pred_sr = d_loss.detach(), pred_gt.detach(), pred_sr.detach()

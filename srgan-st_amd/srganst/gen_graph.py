@@ -56,6 +56,20 @@ def _packs(module, p, mode):
     return dict(zip(names, ops.packed_weights(cache, ("pack", mode), ws, [mode] * len(ws))))
 
 
+def _bn_accumulators(module, nblocks, C, device, zero):
+    """The fp64 statistics accumulators of the accumulator mode, forward [2*nblocks+1][NREP][C][2] and backward
+    [2*nblocks][NREP][C][4], as views of ONE buffer so that one fill at the start of the forward clears both."""
+    nf, nbk = (2 * nblocks + 1) * ops.ACC_NREP * C * 2, 2 * nblocks * ops.ACC_NREP * C * 4
+    buf = module.__dict__.get("_bn_acc_buf")
+    if buf is None or buf.numel() != nf + nbk or buf.device != device:
+        buf = module.__dict__["_bn_acc_buf"] = torch.zeros(nf + nbk, device=device, dtype=torch.float64)
+    if zero == "all":
+        buf.zero_()
+    elif zero == "bwd":
+        buf[nf:].zero_()
+    return buf[:nf].view(2 * nblocks + 1, ops.ACC_NREP, C, 2), buf[nf:].view(2 * nblocks, ops.ACC_NREP, C, 4)
+
+
 def forward(module, x, params, need_grad):
     p = _P(module, params)
     training = module.training
@@ -89,10 +103,8 @@ def forward(module, x, params, need_grad):
         # ---- accumulator mode: no BatchNorm finalize launches - each conv adds its output statistics into fp64 accumulators and
         # the NEXT conv derives the affine of its input from them in its prologue (csrc/conv_epilogue.h: BandAcc)
         nbn = 2 * len(module.trunk) + 1
-        acc = module.__dict__.get("_bn_acc")
-        if acc is None or acc.shape != (nbn, ops.ACC_NREP, C, 2) or acc.device != z1.device:
-            acc = module.__dict__["_bn_acc"] = torch.zeros(nbn, ops.ACC_NREP, C, 2, device=z1.device, dtype=torch.float64)
-        acc.zero_()
+        acc, _ = _bn_accumulators(module, len(module.trunk), C, z1.device, zero="all")
+        sv["acc_token"] = module.__dict__["_bn_acc_token"] = object()      # backward: its accumulators are still clear
 
         def stat_tensors():
             return tuple(ops._f32(C, like=z1) for _ in range(4))
@@ -232,10 +244,9 @@ def backward(module, params, sv, dsr, need_dx=False):
     if nb and ops.conv_acc_supported(Bq, Hq, Wq, C, C):
         # ---- accumulator mode: every data-gradient conv adds the BatchNorm-backward sums of its result into fp64 accumulators,
         # the next stage derives its coefficients from them in its prologue (no finalize launches between the stages)
-        bacc = module.__dict__.get("_bn_bw_acc")
-        if bacc is None or bacc.shape != (2 * nb, ops.ACC_NREP, C, 4) or bacc.device != y3.device:
-            bacc = module.__dict__["_bn_bw_acc"] = torch.zeros(2 * nb, ops.ACC_NREP, C, 4, device=y3.device, dtype=torch.float64)
-        bacc.zero_()
+        _, bacc = _bn_accumulators(module, nb, C, y3.device, zero="bwd" if sv.get("acc_token") is None or
+                                   module.__dict__.get("_bn_acc_token") is not sv.get("acc_token") else None)
+        module.__dict__["_bn_acc_token"] = None          # the backward accumulators are dirty from here on
         dh, _ = ops.conv_dgrad_fused_acc(dy3, wd["conv2.0.weight"], C, 3, epi_y=sv["blocks"][-1][6], bw_st_acc=bacc[2 * nb - 1])
         for i in reversed(range(nb)):
             pre = f"trunk.{i}.rcb"

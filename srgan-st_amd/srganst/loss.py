@@ -141,6 +141,7 @@ class _CriterionSumFn(torch.autograd.Function):
         ctx.terms, ctx.weights, ctx.gS = terms, [float(w) for w in weights], saved
         ctx.save_for_backward(sr, gt)
         ctx.mark_non_differentiable(weighted)
+        ctx.set_materialize_grads(False)                 # no zeros kernel for the gradient slot of `weighted`
         return total, weighted
 
     @staticmethod
