@@ -261,6 +261,33 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     }
   }
 
+  // ---- epilogue operands (wave w finalises blocks w, w+4, w+8: lane -> pixel blk*16 + lane%16, output channels
+  // 16g + 4*(lane/16) .. +3): addresses now, and the epilogue's global reads (residual, bias, epi_y + its affine) are
+  // issued here so that their latency hides behind the K loop instead of following the cross-wave reduction
+  constexpr int MYB = (NB + 3) / 4;
+  const int c0 = g * 16 + 4 * lj;
+  size_t obase[MYB];
+  bool have[MYB];
+  f32x4 pre_res[MYB], pre_ey[MYB];
+  f32x4 pre_bias = {0.f, 0.f, 0.f, 0.f}, esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
+  const bool epi_sums = FUSED && (a.epi_partial || ba.bw_st_acc);
+#pragma unroll
+  for (int i = 0; i < MYB; ++i) {
+    const int blk = wave + 4 * i;
+    have[i] = blk < NB;
+    const int n = blk * 16 + lp16;
+    const int r = n / W, c = n - r * W;
+    obase[i] = have[i] ? (((size_t)b * a.H + y0 + r) * W + c) * a.Cout + c0 : 0;
+    pre_res[i] = pre_ey[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (have[i] && a.residual) pre_res[i] = *reinterpret_cast<const f32x4*>(a.residual + obase[i]);
+    if (have[i] && epi_sums) pre_ey[i] = *reinterpret_cast<const f32x4*>(a.epi_y + obase[i]);
+  }
+  if (a.bias) pre_bias = *reinterpret_cast<const f32x4*>(a.bias + c0);
+  if (epi_sums && a.epi_scale) {
+    esc = *reinterpret_cast<const f32x4*>(a.epi_scale + c0);
+    esh = *reinterpret_cast<const f32x4*>(a.epi_shift + c0);
+  }
+
   f32x4 acc[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -296,19 +323,12 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
   for (int k = 0; k < NB; ++k) *reinterpret_cast<f32x4*>(&lds[((wave * NB + k) * 64 + lane) * 4]) = acc[k];
   __syncthreads();
 
-  // wave w finalises blocks w, w+4, w+8: lane -> pixel blk*16 + lane%16, output channels 16g + 4*(lane/16) .. +3
-  constexpr int MYB = (NB + 3) / 4;
   const int npx = R * W;
-  const int c0 = g * 16 + 4 * lj;
   f32x4 v[MYB];
-  size_t obase[MYB];
-  bool have[MYB];
 #pragma unroll
   for (int i = 0; i < MYB; ++i) {
     const int blk = wave + 4 * i;
-    have[i] = blk < NB;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    obase[i] = 0;
     if (have[i]) {
       f32x4 s = *reinterpret_cast<const f32x4*>(&lds[((0 * NB + blk) * 64 + lane) * 4]);
 #pragma unroll
@@ -316,11 +336,8 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
         const f32x4 t = *reinterpret_cast<const f32x4*>(&lds[((w * NB + blk) * 64 + lane) * 4]);
         s += t;
       }
-      if (a.bias) s += *reinterpret_cast<const f32x4*>(a.bias + c0);
-      const int n = blk * 16 + lp16;
-      const int r = n / W, c = n - r * W;
-      obase[i] = (((size_t)b * a.H + y0 + r) * W + c) * a.Cout + c0;
-      if (a.residual) s += *reinterpret_cast<const f32x4*>(a.residual + obase[i]);
+      s += pre_bias;
+      s += pre_res[i];
       *reinterpret_cast<f32x4*>(a.y + obase[i]) = s;
       v[i] = s;
     }
@@ -395,21 +412,16 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     }
   }
 
-  if (FUSED && (a.epi_partial || ba.bw_st_acc)) {
+  if (epi_sums) {
     // backward partials of the stored g against epi_y (see Conv3Args): sums of (gz, gz*y, g*min(z,0)) over the band
     const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
-    f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
-    if (a.epi_scale) {
-      esc = *reinterpret_cast<const f32x4*>(a.epi_scale + c0);
-      esh = *reinterpret_cast<const f32x4*>(a.epi_shift + c0);
-    }
     f32x4 q[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) q[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MYB; ++i) {
       if (!have[i]) continue;
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(a.epi_y + obase[i]);
+      const f32x4 yv = pre_ey[i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float gq = v[i][j];
