@@ -31,7 +31,10 @@ for (B, H, W, Cin, Cout, s) in shapes:
     dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
     flops = 2.0 * B * ho * wo * Cin * Cout * 9
     print(f"wgrad B{B} {H}x{W} {Cin}->{Cout} s{s}: {flops/1e9:.2f} GFLOP")
-    for name, dbg in [("full", 0), ("no loads", 1), ("no mfma", 2), ("no store", 4), ("loads only", 6), ("mfma only", 5), ("empty", 7)]:
+    variants = [("full", 0), ("no loads", 1), ("no mfma", 2), ("no store", 4), ("loads only", 6), ("mfma only", 5), ("empty", 7)]
+    if os.environ.get("SST_ONLY_FULL"):
+        variants = variants[:1]
+    for name, dbg in variants:
         os.environ["SST_WGRAD_DBG"] = str(dbg)
         t = timeit(lambda: ops.conv_wgrad(x, dy, dw, 3, s))
         print(f"   {name:12s} {t:8.1f} us  {flops/t/1e6:7.1f} TF/s-eq")
