@@ -167,7 +167,8 @@ class WarmupEngine:
 class TrainEngine:
     """reference train.py:16-164 without loaders / logging / validation around the step."""
 
-    def __init__(self, config, generator, discriminator, use_graph=None, process_group=None, adam_capturable=None):
+    def __init__(self, config, generator, discriminator, use_graph=None, process_group=None, adam_capturable=None,
+                 force_dp=False):
         from .loss import BCEWithLogitsLoss
         self.config = config
         self.G, self.D = generator, discriminator
@@ -186,7 +187,8 @@ class TrainEngine:
         self.loss_values = OrderedDict()
         self.d_loss = self.pred_gt = self.pred_sr = None
         g = use_graph
-        if self.world > 1:
+        self.dp = self.world > 1 or force_dp     # force_dp: the split-graph + collective path even with one rank (tests)
+        if self.dp:
             self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g), _GraphedStep(self.g_opt.step, enabled=g)
             self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g), _GraphedStep(self.d_opt.step, enabled=g)
         else:
@@ -247,14 +249,14 @@ class TrainEngine:
             self.gt.copy_(gt, non_blocking=True)
             self.lr.copy_(lr, non_blocking=True)
         self._g_fb()
-        if self.world > 1:
-            sdist.allreduce_module_grads(self.G, self.pg)
+        if self.dp:
+            sdist.allreduce_module_grads(self.G, self.pg, force=True)
             self._g_op()
         did_d = False
         if self.batch_num % self.config.SOLVER.D_UPDATE_INTERVAL == 0:
             self._d_fb()
-            if self.world > 1:
-                sdist.allreduce_module_grads(self.D, self.pg, buckets=2 if self.config.DIST.BUCKET_D else 1)
+            if self.dp:
+                sdist.allreduce_module_grads(self.D, self.pg, buckets=2 if self.config.DIST.BUCKET_D else 1, force=True)
                 self._d_op()
             did_d = True
         self.batch_num += 1

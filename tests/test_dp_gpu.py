@@ -127,6 +127,25 @@ def _nccl_worker(port, q):
         torch.cuda.synchronize()
         assert eng._fb.graph is not None, "hipGraph capture fell back to eager next to a live RCCL communicator"
         out.append({k: v.cpu().numpy() for k, v in G.state_dict().items()})
+    # the full G + D step (train.py:100-164): [G fwd+bwd graph] -> all-reduce -> [G Adam] -> [D fwd+bwd graph] -> 2-bucket all-reduce -> [D Adam]
+    from srganst.engine import TrainEngine
+    from srganst.model import Discriminator
+    for force_dp in (False, True):
+        cfg, G = _make(seed=6)
+        cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+        cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+        cfg.SOLVER.D_UPDATE_INTERVAL = 1
+        torch.manual_seed(7)
+        D = Discriminator(cfg).to("cuda:0").train()
+        eng = TrainEngine(cfg, G, D, use_graph=True, adam_capturable=True, force_dp=force_dp)
+        for step in range(4):
+            g = torch.Generator().manual_seed(50 + step)           # the discriminator is fixed to 96 x 96 inputs (model.py:31-34)
+            eng.step(torch.rand(2, 3, 96, 96, generator=g).cuda(), torch.rand(2, 3, 24, 24, generator=g).cuda())
+        torch.cuda.synchronize()
+        assert eng._g_fb.graph is not None and eng._d_fb.graph is not None
+        sd = {"G." + k: v.cpu().numpy() for k, v in G.state_dict().items()}
+        sd.update({"D." + k: v.cpu().numpy() for k, v in D.state_dict().items()})
+        out.append(sd)
     q.put(out)
     td.barrier()
     td.destroy_process_group()
@@ -139,8 +158,10 @@ def test_graph_capture_next_to_rccl_communicator():
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
     p.start()
-    a, b = q.get(timeout=300)
+    a, b, c, d = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0
     for k in a:
         assert (a[k] == b[k]).all(), k
+    for k in c:
+        assert (c[k] == d[k]).all(), k
