@@ -79,7 +79,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     // All 64 lanes load: lane = (channel j = lane % 16, part = lane / 16) takes replicas part, part + 4, ... (independent
     // 16-B loads); the 4 parts are combined in fixed order with shuffles; lane j < 16 of wave w then owns channel 16w + j.
     typedef double f64x2 __attribute__((ext_vector_type(2)));
-    constexpr int MAXR = 8;                                 // replicas per lane (nrep <= 32)
+    constexpr int MAXR = 4;                                 // replicas per lane (nrep <= 16, checked by the entry points)
     f64x2 accv[MAXR];
     float pre_g = 0.f, pre_b = 0.f;                       // gamma / beta of the lane's channel: in flight with the accumulators
     if (ba.in_acc) {
@@ -131,8 +131,11 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
       if (ba.in_target == 0) { sc = s4; sh = t4; have_aff = true; }
       else { kB = s4; kC = t4; have_k = true; }
     };
-    if (ba.in_acc) affine_from_acc();     // before the patch loads (reducing it after issuing them was measured: the compiler
-                                          // spills in every variant tried, 3x slower)
+    // FUSED instance: reduce before the patch loads (reducing after issuing them was measured there: the compiler spills in every
+    // variant tried, 3x slower).  Plain forward instance (92 VGPRs): the accumulator loads were issued first, so the reduction
+    // only waits for them (in-order vmcnt) while the patch loads issued below stay in flight behind it.
+    constexpr bool LATE_ACC = !FUSED;
+    if (ba.in_acc && !LATE_ACC) affine_from_acc();
     if (FUSED && ba.bw_in_acc) {
       // BatchNorm-backward coefficients of the input from the producer's accumulators [nrep][64][4] (same lane mapping)
       double S0 = 0.0, S1 = 0.0, S2 = 0.0;
@@ -140,9 +143,9 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
                   ga = ba.bw_gamma[wave * 16 + (lane & 15)];          // in flight with the accumulator loads
       {
         const int ch = wave * 16 + (lane & 15), part = lane >> 4;
-        f64x2 v0[MAXR / 2], v1[MAXR / 2];
+        f64x2 v0[MAXR], v1[MAXR];
 #pragma unroll
-        for (int k = 0; k < MAXR / 2; ++k) {                 // nrep <= 16 here
+        for (int k = 0; k < MAXR; ++k) {
           const int r = part + 4 * k;
           v0[k] = v1[k] = f64x2{0.0, 0.0};
           if (r < ba.nrep) {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
           }
         }
 #pragma unroll
-        for (int k = 0; k < MAXR / 2; ++k) { S0 += v0[k][0]; S1 += v0[k][1]; S2 += v1[k][0]; }
+        for (int k = 0; k < MAXR; ++k) { S0 += v0[k][0]; S1 += v0[k][1]; S2 += v1[k][0]; }
         S0 += __shfl_xor(S0, 16, 64); S1 += __shfl_xor(S1, 16, 64); S2 += __shfl_xor(S2, 16, 64);
         S0 += __shfl_xor(S0, 32, 64); S1 += __shfl_xor(S1, 32, 64); S2 += __shfl_xor(S2, 32, 64);
       }
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
     int py = p / PW, px = p - py * PW;
     constexpr int UN = 7;      // 24x24: the 104-pixel patch is ONE batch of loads (two batches = two exposed latencies)
     const int nit = (a.dbg & 1) ? 0 : (npatch + 15) / 16;
-    for (int it0 = 0; it0 < nit; it0 += UN) {
+    auto do_batch = [&](const int it0, const bool late) {
       f32x4 v[UN], yv[UN];
       int off[UN], lp[UN];
       bool ok[UN], own[UN];
@@ -204,22 +207,23 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
         own[u] = py >= 1 && py <= R;
         lp[u] = p < npatch ? p : -1;
         off[u] = (iy * W + ix) * 64;
-        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // branch-free loads (padding slots read the image origin, in bounds, and are zeroed below): straight-line code keeps
+        // the compiler's vmcnt waits counted, so the accumulator reduction does not wait for the patch
+        const int ldo = ok[u] ? off[u] : 0;
+        v[u] = *reinterpret_cast<const f32x4*>(xb + ldo);
         yv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok[u]) {
-          v[u] = *reinterpret_cast<const f32x4*>(xb + off[u]);
-          if (x2b) yv[u] = *reinterpret_cast<const f32x4*>(x2b + off[u]);
-        }
+        if (x2b) yv[u] = *reinterpret_cast<const f32x4*>(x2b + ldo);
         p += 16;
         px += 16;
         if (px >= PW) { px -= PW; ++py; }
         if (px >= PW) { px -= PW; ++py; }
       }
+      if (late) affine_from_acc();
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         if (lp[u] < 0 || it0 + u >= nit) continue;
         f32x4 t = v[u];
-        if (ok[u]) {
+        {
           if (x2b) {                        // fused BatchNorm-backward apply (see Conv3Args)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
               }
               t[j] = have_k ? fmaf(kA[j], gz, fmaf(kB[j], yv[u][j], kC[j])) : gz;
             }
-            if (sob && own[u]) *reinterpret_cast<f32x4*>(sob + off[u]) = t;
+            if (sob && own[u] && ok[u]) *reinterpret_cast<f32x4*>(sob + off[u]) = t;
           } else {
             if (have_aff) {
 #pragma unroll
@@ -242,8 +246,15 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
             }
           }
         }
+        if (!ok[u]) t = f32x4{0.f, 0.f, 0.f, 0.f};            // padding stays exactly zero
         *reinterpret_cast<f32x4*>(&P[lp[u] * PSTR + q4]) = t;
       }
+    };
+    if (LATE_ACC && ba.in_acc && nit <= UN) {
+      do_batch(0, true);                  // one batch of loads: accumulator reduction behind them
+    } else {
+      if (LATE_ACC && ba.in_acc) affine_from_acc();
+      for (int it0 = 0; it0 < nit; it0 += UN) do_batch(it0, false);
     }
   }
 

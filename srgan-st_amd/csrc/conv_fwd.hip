@@ -601,7 +601,7 @@ SST_API int sst_conv_fwd_acc(const float* x, const float* in2, float* side_out, 
                              float* o_rstd, float* o_scale, float* o_shift, float* run_mean, float* run_var, double* st_acc,
                              int nrep, int B, int H, int W, int Cin, int Cout, int ksize, void* stream) {
   SST_REQUIRE(sst_conv_acc_supported(B, H, W, Cin, Cout, ksize, 1), "sst_conv_fwd_acc: shape not covered by the band kernel");
-  SST_REQUIRE(nrep > 0 && (in_acc || st_acc), "sst_conv_fwd_acc: no accumulator given");
+  SST_REQUIRE(nrep > 0 && nrep <= 16 && (in_acc || st_acc), "sst_conv_fwd_acc: no accumulator given / nrep > 16");
   SST_REQUIRE(!in_acc || (in_gamma && in_beta && in_n > 0.f), "sst_conv_fwd_acc: in_acc needs gamma / beta / n");
   SST_REQUIRE(!in2 || (side_out && ones), "sst_conv_fwd_acc: residual form needs side_out and the ones vector");
   BandAcc ba{};
