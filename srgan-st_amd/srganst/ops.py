@@ -137,7 +137,7 @@ def conv_fwd_resin(x, y2, bn_scale, bn_shift, wp, cout, ksize=3, bias=None, want
     return y, h, stats, cnt
 
 
-ACC_NREP = 16     # replicas of the fp64 BatchNorm accumulators (images are spread over them)
+ACC_NREP = int(os.environ.get("SST_ACC_NREP", "16"))     # replicas of the fp64 BatchNorm accumulators (images are spread over them)
 
 
 def conv_acc_supported(B, H, W, cin, cout, ksize=3, stride=1):
