@@ -12,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def base(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return re.sub(r"\(.*$", "", name).strip()
+    name = re.sub(r"\(.*$", "", name).strip()
+    # bench.py labels the band conv family by its pixel-block count only; rocprofv3 lists the two instantiations
+    # (<NB, true> two-tensor / backward forms, <NB, false> plain forward) separately: merged here, weighted by launches
+    return re.sub(r"conv_band_kernel<(\d+), (true|false)>", r"conv_band_kernel<\1>", name)
 
 
 def collect(d, counter):
