@@ -212,3 +212,34 @@ def test_train_engine_graph_equals_eager():
     for k in d1:
         assert torch.equal(d1[k], d2[k]), k
     assert l1 == l2
+
+
+def test_discriminator_hr192_vs_oracle():
+    """BASELINE configs[4]: 192 px crops.  The reference hard-codes 96 px (model.py:31-34, classifier in-features 512*6*6); the
+    build derives them from DATA.GT_IMAGE_SIZE (8C * (HR/16)^2 = 73,728).  Logits, input gradient and every parameter
+    gradient against the CPU oracle built for the same image size."""
+    from oracle import model as om
+    from srganst.model import Discriminator
+    from srganst.loss import BCEWithLogitsLoss
+    cfg = make_cfg()
+    cfg.DATA.GT_IMAGE_SIZE = 192
+    torch.manual_seed(17)
+    D = Discriminator(cfg)
+    assert D.state_dict()["classifier.0.weight"].shape == (1024, 73728)
+    gen = torch.Generator().manual_seed(18)
+    x = torch.rand(2, 3, 192, 192, generator=gen)
+    sd = {k: v.clone() for k, v in D.state_dict().items()}
+    for k in om.param_keys(sd):
+        sd[k].requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    logit_ref = om.discriminator_forward(sd, xr, True, {})
+    target = torch.full([2, 1], 0.9)
+    F.binary_cross_entropy_with_logits(logit_ref, target).backward()
+    D.cuda().train()
+    xg = x.cuda().requires_grad_(True)
+    logit = D(xg)
+    BCEWithLogitsLoss()(logit, target.cuda()).backward()
+    assert torch.allclose(logit.detach().cpu(), logit_ref.detach(), rtol=1e-3, atol=1e-4)
+    assert rel_err(xg.grad.cpu(), xr.grad) < 5e-3
+    for n, p in D.named_parameters():
+        assert rel_err(p.grad.cpu(), sd[n].grad) < 5e-3, n

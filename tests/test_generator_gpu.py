@@ -165,3 +165,35 @@ def test_accumulator_mode_equals_partial_tile_mode(monkeypatch):
             assert rel_err(gr_a[n], gr_b[n]) < tol, n
         for k in bn_a:
             assert torch.allclose(bn_a[k], bn_b[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_generator_vs_oracle_hr192():
+    """BASELINE configs[4] shape (48 -> 192 px HR crops): the trunk runs the band kernel with one-row bands (W = 48) and the
+    up-sampler the 64x64-tile kernel at 96 px; SR, both losses and every gradient against the CPU oracle."""
+    from oracle import model as om
+    from oracle import st as ost
+    from srganst import _abi
+    from srganst.model import Generator
+    from srganst.loss import MSELoss, StructureTensorLoss
+    torch.manual_seed(13)
+    G = Generator(make_cfg(64, 2))
+    gen = torch.Generator().manual_seed(14)
+    lr = torch.rand(2, 3, 48, 48, generator=gen)
+    gt = torch.rand(2, 3, 192, 192, generator=gen)
+    sd = {k: v.clone() for k, v in G.state_dict().items()}
+    for k in om.param_keys(sd):
+        sd[k].requires_grad_(True)
+    sr_ref = om.generator_forward(sd, lr, True, {})
+    l_ref = torch.nn.functional.mse_loss(sr_ref, gt) + ost.st_loss(sr_ref, gt) / 3
+    l_ref.backward()
+    n0 = _abi.lib().sst_debug_band_launches()
+    G.cuda().train()
+    sr = G(lr.cuda())
+    loss = MSELoss()(sr, gt.cuda()) + StructureTensorLoss()(sr, gt.cuda()) * (1 / 3)
+    loss.backward()
+    assert _abi.lib().sst_debug_band_launches() - n0 >= 8          # 5 forward + 5 backward trunk convs
+    assert sr.shape == (2, 3, 192, 192)
+    assert rel_err(sr.detach().cpu(), sr_ref.detach()) < 1e-3
+    assert abs(loss.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
+    for n, p in G.named_parameters():
+        assert rel_err(p.grad.cpu(), sd[n].grad) < 5e-3, n
