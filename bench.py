@@ -16,7 +16,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "srgan-st_amd")):
+for p in (ROOT, os.environ.get("SST_PKG_ROOT") or os.path.join(ROOT, "srgan-st_amd")):     # SST_PKG_ROOT: dev A/B of two package trees
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -372,26 +372,14 @@ __global__ __launch_bounds__(CONV_NT) void conv9_c3_fwd_kernel(C3FwdArgs a) {
 // w [Cout][Cin][9][9] -> packed for conv9_c3_fwd.  mode 0: Cin must be 3 (conv1 forward).
 // mode 1: Cout must be 3 (data-gradient of conv3): outputs = Cin, inputs = Cout, taps rotated 180 degrees.
 __global__ void pack_c3_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int mode) {
-  const int O = mode ? Cin : Cout;
-  const int total = ((O + 31) / 32) * 36 * 256;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int jj = idx & 3, l = (idx >> 2) & 63;
-    const int chunk = (idx >> 8) % 36, of = (idx >> 8) / 36;
-    const int ky = chunk >> 2, c4 = chunk & 3;
-    const int o = of * 32 + (l & 31), j = c4 * 8 + (l >> 5) * 4 + jj;
-    float v = 0.f;
-    if (o < O && j < 27) {
-      const int kx = j / 3, ch = j - 3 * kx;
-      v = mode == 0 ? w[(((size_t)o * Cin + ch) * 9 + ky) * 9 + kx]
-                    : w[(((size_t)ch * Cin + o) * 9 + (8 - ky)) * 9 + (8 - kx)];
-    }
-    wp[idx] = v;
-  }
+  const int total = (int)c3_packed_floats(mode ? Cin : Cout);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+    wp[idx] = pack_c3_value(w, idx, Cout, Cin, mode);
 }
 
 }  // namespace
 
-SST_API int64_t sst_conv9_c3_packed_floats(int Cout_eff) { return (int64_t)((Cout_eff + 31) / 32) * 36 * 256; }
+SST_API int64_t sst_conv9_c3_packed_floats(int Cout_eff) { return c3_packed_floats(Cout_eff); }
 
 SST_API int sst_conv9_c3_pack(const float* w, float* wp, int Cout, int Cin, int mode, void* stream) {
   SST_REQUIRE(w && wp && Cout > 0 && Cin > 0 && (mode == 0 ? Cin == 3 : Cout == 3), "sst_conv9_c3_pack: the 3-channel side is missing");
@@ -543,23 +531,13 @@ __global__ __launch_bounds__(T3_NT) void conv9_to3_fwd_kernel(To3Args a) {
 
 // w [3][C][9][9] -> packed [ncb][ky][ks 0..7][lane][4]: B[k=(ky,ci)][n=3kx+co] (+ PACK_PAD zeros at the end)
 __global__ void pack_to3_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int64_t total) {
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int jj = idx & 3, l = (idx >> 2) & 63, ks = (idx >> 8) & 7;
-    const int64_t rest = idx >> 11;
-    const int ky = (int)(rest % 9), cb = (int)(rest / 9);
-    const int q = l & 31, ci = cb * 64 + ks * 8 + (l >> 5) * 4 + jj;
-    float v = 0.f;
-    if (cb < (C + 63) / 64 && q < 27 && ci < C) {
-      const int kx = q / 3, co = q - 3 * kx;
-      v = w[(((size_t)co * C + ci) * 9 + ky) * 9 + kx];
-    }
-    wp[idx] = v;
-  }
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+    wp[idx] = pack_to3_value(w, idx, C);
 }
 
 }  // namespace
 
-SST_API int64_t sst_conv9_to3_packed_floats(int C) { return (int64_t)((C + 63) / 64) * 9 * 8 * 256 + PACK_PAD; }
+SST_API int64_t sst_conv9_to3_packed_floats(int C) { return to3_packed_floats(C); }
 
 SST_API int sst_conv9_to3_pack(const float* w, float* wp, int C, void* stream) {
   SST_REQUIRE(w && wp && C > 0, "sst_conv9_to3_pack: bad argument");

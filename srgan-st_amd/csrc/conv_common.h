@@ -38,3 +38,29 @@ __host__ __device__ inline int64_t band_index(int o, int i, int tap) {
 __host__ __device__ inline int64_t packed_floats(int cout, int cin, int kk) {
   return packed_floats_base(cout, cin, kk) + (band_eligible(cout, cin, kk) ? (int64_t)cout * cin * 9 : 0);
 }
+
+// 9x9 convs with a 3-channel side (conv9_c3.hip): packed value at flat index idx.  Shared by the stand-alone pack kernels and
+// the multi-tensor pack (conv_fwd.hip: PackJob modes 2..4), so that one launch packs every weight of a network.
+//   c3 (mode 0: w [Cout][3][9][9] conv1 forward; mode 1: w [3][C][9][9] data-gradient of conv3): [O/32][36 chunks][64 lanes][4]
+__host__ __device__ inline int64_t c3_packed_floats(int O) { return (int64_t)((O + 31) / 32) * 36 * 256; }
+__device__ inline float pack_c3_value(const float* __restrict__ w, int64_t idx, int Cout, int Cin, int mode) {
+  const int O = mode ? Cin : Cout;
+  const int jj = idx & 3, l = (idx >> 2) & 63;
+  const int chunk = (int)((idx >> 8) % 36), of = (int)((idx >> 8) / 36);
+  const int ky = chunk >> 2, c4 = chunk & 3;
+  const int o = of * 32 + (l & 31), j = c4 * 8 + (l >> 5) * 4 + jj;
+  if (o >= O || j >= 27) return 0.f;
+  const int kx = j / 3, ch = j - 3 * kx;
+  return mode == 0 ? w[(((size_t)o * Cin + ch) * 9 + ky) * 9 + kx] : w[(((size_t)ch * Cin + o) * 9 + (8 - ky)) * 9 + (8 - kx)];
+}
+//   to3 (w [3][C][9][9], conv3 forward): [C/64][ky][ks 0..7][64 lanes][4] = B[k = (ky, ci)][n = 3 kx + co]  (+ PACK_PAD zeros)
+__host__ __device__ inline int64_t to3_packed_floats(int C) { return (int64_t)((C + 63) / 64) * 9 * 8 * 256 + PACK_PAD; }
+__device__ inline float pack_to3_value(const float* __restrict__ w, int64_t idx, int C) {
+  const int jj = idx & 3, l = (idx >> 2) & 63, ks = (idx >> 8) & 7;
+  const int64_t rest = idx >> 11;
+  const int ky = (int)(rest % 9), cb = (int)(rest / 9);
+  const int q = l & 31, ci = cb * 64 + ks * 8 + (l >> 5) * 4 + jj;
+  if (cb >= (C + 63) / 64 || q >= 27 || ci >= C) return 0.f;
+  const int kx = q / 3, co = q - 3 * kx;
+  return w[(((size_t)co * C + ci) * 9 + ky) * 9 + kx];
+}

@@ -345,6 +345,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
     if (jobs[mid].block_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const PackJob jb = jobs[lo];
+  if (jb.mode >= 2) {                               // 9x9 convs with a 3-channel side: 2 / 3 = c3 mode 0 / 1, 4 = to3
+    const long long base = ((long long)blockIdx.x - jb.block_begin) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long idx = base + u * 256 + threadIdx.x;
+      if (idx >= jb.total) break;
+      jb.wp[idx] = jb.mode == 4 ? pack_to3_value(jb.w, idx, jb.Cin) : pack_c3_value(jb.w, idx, jb.Cout, jb.Cin, jb.mode - 2);
+    }
+    return;
+  }
   const int O = jb.mode ? jb.Cin : jb.Cout, I = jb.mode ? jb.Cout : jb.Cin;
   const int ncb = (I + 63) / 64;
   const long long base = ((long long)blockIdx.x - jb.block_begin) * 1024;
@@ -428,7 +438,8 @@ SST_API int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksiz
   return SST_OK;
 }
 
-// jobs: device array of {w, wp, Cout, Cin, KK, mode, total, block_begin} (8 x 8 bytes each, see srganst/ops.py)
+// jobs: device array of {w, wp, Cout, Cin, KK, mode, total, block_begin} (8 x 8 bytes each, see srganst/ops.py);
+// mode 0 / 1: forward / data-gradient layout of a k x k conv; 2 / 3: sst_conv9_c3_pack mode 0 / 1; 4: sst_conv9_to3_pack
 SST_API int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, void* stream) {
   SST_REQUIRE(jobs && njobs > 0 && total_blocks > 0, "sst_conv_pack_multi: bad argument");
   static_assert(sizeof(PackJob) == 48, "PackJob layout");

@@ -48,12 +48,31 @@ def _conv_names(module, fast9):
     return names
 
 
-def _packs(module, p, mode):
-    """name -> packed weight (mode 0 forward / mode 1 data-gradient); one multi-tensor launch."""
+def _packs(module, p, with_dgrad):
+    """All packed weights of the generator from ONE multi-tensor launch: (forward packs by name, data-gradient packs by name or
+    None, packs of the (kx, 3ch)-folded 9x9 kernels {"conv1", "conv3", "conv3.dgrad"}).  The data-gradient packs are made by
+    the training forward and handed to backward() (the weights do not change in between)."""
     cache = module.__dict__.setdefault("_hip_cache", {})
-    names = _conv_names(module, _fast9(module, p))
+    fast9 = _fast9(module, p)
+    names = _conv_names(module, fast9)
     ws = [p[n] for n in names]
-    return dict(zip(names, ops.packed_weights(cache, ("pack", mode), ws, [mode] * len(ws))))
+    modes = [ops.PACK_FWD] * len(ws)
+    if with_dgrad:
+        ws += [p[n] for n in names]
+        modes += [ops.PACK_DGRAD] * len(names)
+    nine = []
+    if fast9:
+        nine = [("conv1", "conv1.0.weight", ops.PACK_C3_FWD), ("conv3", "conv3.weight", ops.PACK_TO3)]
+        if with_dgrad:
+            nine.append(("conv3.dgrad", "conv3.weight", ops.PACK_C3_DGRAD))
+        ws += [p[n] for _, n, _ in nine]
+        modes += [m for _, _, m in nine]
+    out = ops.packed_weights(cache, ("pack", bool(with_dgrad)), ws, modes)
+    k = len(names)
+    wp = dict(zip(names, out[:k]))
+    wd = dict(zip(names, out[k:2 * k])) if with_dgrad else None
+    w9 = {key: t for (key, _, _), t in zip(nine, out[(2 * k if with_dgrad else k):])}
+    return wp, wd, w9
 
 
 def _bn_accumulators(module, nblocks, C, device, zero):
@@ -75,13 +94,14 @@ def forward(module, x, params, need_grad):
     training = module.training
     sv = {}                                       # saved for backward
     C = p["conv1.0.weight"].shape[0]
-    wp = _packs(module, p, 0)
+    wp, sv["wd"], w9 = _packs(module, p, need_grad)
+    sv["w9"] = w9
     if training:
         ops.flatten_bn_counters(module).add_(1)
     x3 = ops.transpose(x.contiguous(), to_nchw=False)                                  # [B,h,w,3]
     fast9 = _fast9(module, p)
     if fast9:
-        z1 = ops.conv9_c3_fwd(x3, p["conv1.0.weight"], 0, bias=p["conv1.0.bias"])
+        z1 = ops.conv9_c3_fwd(x3, p["conv1.0.weight"], 0, bias=p["conv1.0.bias"], wp=w9["conv1"])
     else:
         z1, _, _, _ = ops.conv_fwd(x3, wp["conv1.0.weight"], C, 9, 1, bias=p["conv1.0.bias"])
     a1 = p["conv1.1.weight"]
@@ -185,7 +205,7 @@ def forward(module, x, params, need_grad):
     cout = p["conv3.weight"].shape[0]
     if fast9:
         sr, sr_pre = ops.conv9_to3_fwd(u, p["conv3.weight"], bias=p["conv3.bias"], in_slope=slope,
-                                       in_act=ACT_SLOPE if slope is not None else 0, want_pre=need_grad)
+                                       in_act=ACT_SLOPE if slope is not None else 0, want_pre=need_grad, wp=w9["conv3"])
     else:
         sr, sr_pre, _, _ = ops.conv_fwd(u, wp["conv3.weight"], cout, 9, 1, bias=p["conv3.bias"], in_slope=slope,
                                         in_act=ACT_SLOPE if slope is not None else 0, out_mode=OUT_NCHW_CLAMP,
@@ -200,7 +220,7 @@ def backward(module, params, sv, dsr, need_dx=False):
     grads = ops.flat_grads(module, module._names, params)      # views of ONE flat buffer (single RCCL message)
     C = p["conv1.0.weight"].shape[0]
     a1 = p["conv1.1.weight"]
-    wd = _packs(module, p, 1)
+    wd, w9 = sv["wd"], sv["w9"]                  # packed by the forward's multi-tensor launch
     wg = ops.WgradGroup()            # the trunk-shaped weight gradients go out as ONE launch at the end
 
     def rows(t):
@@ -216,7 +236,7 @@ def backward(module, params, sv, dsr, need_dx=False):
         else:
             ops.conv_wgrad(u, g3, grads["conv3.weight"], 9, 1, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
     if fast9:
-        g = ops.conv9_c3_fwd(g3, p["conv3.weight"], 1)              # d PReLU(u)
+        g = ops.conv9_c3_fwd(g3, p["conv3.weight"], 1, wp=w9["conv3.dgrad"])              # d PReLU(u)
     else:
         g = ops.conv_fwd(g3, wd["conv3.weight"], C, 9, 1)[0]
     # ---- up-sampling blocks, last to first

@@ -497,6 +497,9 @@ def wgrad_c3_supported(C, ksize=9):
 
 
 # ------------------------------------------------------------------------------------------------
+PACK_FWD, PACK_DGRAD, PACK_C3_FWD, PACK_C3_DGRAD, PACK_TO3 = 0, 1, 2, 3, 4      # PackJob modes (csrc/conv_fwd.hip)
+
+
 class PackPlan:
     """All conv weights of a network packed by ONE kernel launch (sst_conv_pack_multi).  The job table and the
     packed buffers are persistent, so the launch is graph-capturable; rebuild when a parameter moves."""
@@ -507,8 +510,13 @@ class PackPlan:
         self.out, rows, blk = [], [], 0
         for w, m in zip(weights, modes):
             cout, cin, k, _ = w.shape
-            o, i = (cin, cout) if m else (cout, cin)
-            n = _abi.lib().sst_conv_packed_floats(o, i, k)
+            if m == PACK_C3_FWD or m == PACK_C3_DGRAD:          # 9x9 with a 3-channel side (conv9_c3_fwd's layout)
+                n = _abi.lib().sst_conv9_c3_packed_floats(cin if m == PACK_C3_DGRAD else cout)
+            elif m == PACK_TO3:                                 # conv9_to3_fwd's layout
+                n = _abi.lib().sst_conv9_to3_packed_floats(cin)
+            else:
+                o, i = (cin, cout) if m else (cout, cin)
+                n = _abi.lib().sst_conv_packed_floats(o, i, k)
             wp = torch.empty(n, device=dev, dtype=torch.float32)
             self.out.append(wp)
             rows.append([w.data_ptr(), wp.data_ptr(), cout | (cin << 32), (k * k) | (int(m) << 32), n, blk])
@@ -609,13 +617,14 @@ def join_side():
             main.wait_stream(side)
 
 
-def conv9_c3_fwd(x3, w, mode, bias=None):
+def conv9_c3_fwd(x3, w, mode, bias=None, wp=None):
     """9x9 conv from a 3-channel NHWC tensor.  mode 0: w [Cout,3,9,9] (conv1 forward).  mode 1: w [3,C,9,9] and the
-    result is the data-gradient of that conv (C output channels)."""
+    result is the data-gradient of that conv (C output channels).  wp: w already packed (PackPlan mode PACK_C3_*)."""
     B, H, W, _ = x3.shape
     cout = w.shape[1] if mode else w.shape[0]
-    wp = _f32(_abi.lib().sst_conv9_c3_packed_floats(cout), like=w)
-    check(_abi.lib().sst_conv9_c3_pack(ptr(w), ptr(wp), w.shape[0], w.shape[1], mode, stream_ptr()), "sst_conv9_c3_pack")
+    if wp is None:
+        wp = _f32(_abi.lib().sst_conv9_c3_packed_floats(cout), like=w)
+        check(_abi.lib().sst_conv9_c3_pack(ptr(w), ptr(wp), w.shape[0], w.shape[1], mode, stream_ptr()), "sst_conv9_c3_pack")
     y = _f32(B, H, W, cout, like=x3)
     e0 = _prof_begin()
     check(_abi.lib().sst_conv9_c3_fwd(ptr(x3), ptr(wp), ptr(y), ptr(bias), B, H, W, cout, stream_ptr()), "sst_conv9_c3_fwd")
@@ -623,12 +632,14 @@ def conv9_c3_fwd(x3, w, mode, bias=None):
     return y
 
 
-def conv9_to3_fwd(x, w, bias=None, in_slope=None, in_slope_const=0.0, in_act=ACT_NONE, want_pre=False):
-    """x [B,H,W,C] NHWC -> (clamp(conv9x9(act(x)) + bias, 0, 1) as NCHW [B,3,H,W], pre-clamp copy or None)."""
+def conv9_to3_fwd(x, w, bias=None, in_slope=None, in_slope_const=0.0, in_act=ACT_NONE, want_pre=False, wp=None):
+    """x [B,H,W,C] NHWC -> (clamp(conv9x9(act(x)) + bias, 0, 1) as NCHW [B,3,H,W], pre-clamp copy or None).
+    wp: w already packed (PackPlan mode PACK_TO3)."""
     B, H, W, C = x.shape
     assert tuple(w.shape) == (3, C, 9, 9)
-    wp = _f32(_abi.lib().sst_conv9_to3_packed_floats(C), like=w)
-    check(_abi.lib().sst_conv9_to3_pack(ptr(w), ptr(wp), C, stream_ptr()), "sst_conv9_to3_pack")
+    if wp is None:
+        wp = _f32(_abi.lib().sst_conv9_to3_packed_floats(C), like=w)
+        check(_abi.lib().sst_conv9_to3_pack(ptr(w), ptr(wp), C, stream_ptr()), "sst_conv9_to3_pack")
     y = _f32(B, 3, H, W, like=x)
     y_pre = torch.empty_like(y) if want_pre else None
     e0 = _prof_begin()
