@@ -188,9 +188,13 @@ class TrainEngine:
         self.d_loss = self.pred_gt = self.pred_sr = None
         g = use_graph
         self.dp = self.world > 1 or force_dp     # force_dp: the split-graph + collective path even with one rank (tests)
+        # D's packed weights are made once per iteration, by the D(sr) of the generator step, and re-used by the forward and
+        # backward passes of the discriminator step (disc_graph._packs): this engine owns every update of D's weights
+        self.D.__dict__["_packs_managed"] = True
+        self.D.__dict__["_packs_fresh"] = False
         if self.dp:
             self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g), _GraphedStep(self.g_opt.step, enabled=g)
-            self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g), _GraphedStep(self.d_opt.step, enabled=g)
+            self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g), _GraphedStep(self._d_step, enabled=g)
         else:
             self._g_fb, self._g_op = _GraphedStep(self._g_full, enabled=g), None
             self._d_fb, self._d_op = _GraphedStep(self._d_full, enabled=g), None
@@ -201,6 +205,7 @@ class TrainEngine:
         for p in self.D.parameters():
             p.requires_grad = False
         self.g_opt.zero_grad(set_to_none=True)
+        self.D.__dict__["_packs_fresh"] = False      # the generator step always packs D's current weights (also when captured)
         sr = self.G(self.lr)
         total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
                                        adversarial=lambda crit: crit(self.D(sr), self.real))
@@ -232,9 +237,13 @@ class TrainEngine:
         self.d_loss, self.pred_gt, self.pred_sr = d_loss.detach(), pred_gt.detach(), pred_sr.detach()
         return self.d_loss
 
+    def _d_step(self):
+        self.d_opt.step()
+        self.D.__dict__["_packs_fresh"] = False      # weights changed
+
     def _d_full(self):
         v = self._d_fwd_bwd()
-        self.d_opt.step()
+        self._d_step()
         return v
 
     def close(self):

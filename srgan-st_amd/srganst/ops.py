@@ -388,10 +388,11 @@ def bce_logits(logits, target, want_loss=True, want_grad=False, scale_dev=None, 
     return loss, dl
 
 
-def pack_conv_s2_dgrad(w):
+def pack_conv_s2_dgrad(w, out=None):
     cout, cin, k, _ = w.shape
     assert k == 3
-    wp = _f32(_abi.lib().sst_conv_s2_dgrad_packed_floats(cout, cin), like=w)
+    n = _abi.lib().sst_conv_s2_dgrad_packed_floats(cout, cin)
+    wp = out if out is not None and out.numel() == n and out.device == w.device else _f32(n, like=w)
     check(_abi.lib().sst_conv_s2_dgrad_pack(ptr(w), ptr(wp), cout, cin, stream_ptr()), "sst_conv_s2_dgrad_pack")
     return wp
 

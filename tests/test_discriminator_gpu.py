@@ -243,3 +243,37 @@ def test_discriminator_hr192_vs_oracle():
     assert rel_err(xg.grad.cpu(), xr.grad) < 5e-3
     for n, p in D.named_parameters():
         assert rel_err(p.grad.cpu(), sd[n].grad) < 5e-3, n
+
+
+@pytest.mark.parametrize("interval", [1, 2])
+def test_train_engine_pack_reuse_equals_repacking(interval):
+    """The engine lets the discriminator step re-use the weight packs made by the generator step's D(sr) (disc_graph._packs).
+    Same run with the re-use switched off (every pass packs, as outside an engine): parameters, BatchNorm buffers and losses
+    must be bit-identical, with D updated every step and every second step, under hipGraph replay."""
+    from srganst.engine import TrainEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+
+    def run(managed):
+        cfg = make_cfg(16, 2, 8)
+        torch.manual_seed(1)
+        D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
+        cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+        cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+        cfg.SOLVER.D_UPDATE_INTERVAL = interval
+        eng = TrainEngine(cfg, G, D, use_graph=True, adam_capturable=True)
+        if not managed:
+            D.__dict__["_packs_managed"] = False
+        gen = torch.Generator().manual_seed(2)
+        for _ in range(6):
+            eng.step(torch.rand(4, 3, 96, 96, generator=gen).cuda(), torch.rand(4, 3, 24, 24, generator=gen).cuda())
+        torch.cuda.synchronize()
+        return G.state_dict(), D.state_dict(), {k: v.item() for k, v in eng.loss_values.items()}
+
+    g1, d1, l1 = run(True)
+    g2, d2, l2 = run(False)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    for k in d1:
+        assert torch.equal(d1[k], d2[k]), k
+    assert l1 == l2
