@@ -49,7 +49,8 @@ int sst_st_loss_bwd(const float* sr, const float* gS, float* dsr, const float* s
 int64_t sst_conv_packed_floats(int Cout, int Cin, int ksize);
 int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksize, int mode, void* stream);
 /* one launch for many tensors: jobs = device array of {const float* w; float* wp; int Cout, Cin, KK, mode;
- * long long total, block_begin;} (48 bytes each; each workgroup packs 1024 floats) */
+ * long long total, block_begin;} (48 bytes each; each workgroup packs 1024 floats).  mode 0 / 1: sst_conv_pack forward /
+ * data-gradient layout; 2 / 3: sst_conv9_c3_pack mode 0 / 1; 4: sst_conv9_to3_pack (total = the matching *_packed_floats) */
 int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, void* stream);
 int sst_conv_mtiles(int B, int Ho, int Wo);
 /* first dimension of stats / stats_cnt / epi_partial written by the NHWC-store conv of this shape (input H x W):
