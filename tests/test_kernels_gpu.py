@@ -521,3 +521,28 @@ def test_conv_s2_dgrad_fused_stage(ops, case):
     assert rel_err(tot[0], gzp.sum(dim=(0, 2, 3))) < 1e-4
     assert rel_err(tot[1], (gzp * yprev.double()).sum(dim=(0, 2, 3))) < 1e-4
     assert rel_err(tot[2], (dx_ref * zp.clamp(max=0)).sum(dim=(0, 2, 3))) < 1e-4
+
+
+def test_multi_pack_9x9_modes_equal_standalone_packers():
+    """PackPlan modes 2..4 (the (kx, 3ch)-folded layouts of the 9x9 convs inside the multi-tensor pack launch) against the
+    stand-alone pack kernels: bit-identical buffers, next to ordinary forward / data-gradient jobs in the same launch."""
+    from srganst import _abi, ops
+    g = torch.Generator().manual_seed(77)
+    w1 = torch.randn(64, 3, 9, 9, generator=g).cuda()           # conv1
+    w3 = torch.randn(3, 64, 9, 9, generator=g).cuda()           # conv3
+    wt = torch.randn(64, 64, 3, 3, generator=g).cuda()          # a trunk conv riding in the same launch
+    out = ops.PackPlan([wt, w1, w3, w3, wt], [ops.PACK_FWD, ops.PACK_C3_FWD, ops.PACK_TO3, ops.PACK_C3_DGRAD, ops.PACK_DGRAD]).run()
+    lib = _abi.lib()
+
+    def c3(w, mode):
+        o = w.shape[1] if mode else w.shape[0]
+        wp = torch.empty(lib.sst_conv9_c3_packed_floats(o), device="cuda")
+        _abi.check(lib.sst_conv9_c3_pack(_abi.ptr(w), _abi.ptr(wp), w.shape[0], w.shape[1], mode, _abi.stream_ptr()), "pack")
+        return wp
+
+    t3 = torch.empty(lib.sst_conv9_to3_packed_floats(64), device="cuda")
+    _abi.check(lib.sst_conv9_to3_pack(_abi.ptr(w3), _abi.ptr(t3), 64, _abi.stream_ptr()), "pack")
+    assert torch.equal(out[1], c3(w1, 0))
+    assert torch.equal(out[2], t3)
+    assert torch.equal(out[3], c3(w3, 1))
+    assert torch.equal(out[0], ops.pack_conv(wt, 0)) and torch.equal(out[4], ops.pack_conv(wt, 1))
