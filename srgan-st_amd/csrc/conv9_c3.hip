@@ -200,31 +200,41 @@ __global__ __launch_bounds__(CONV_NT, (NU <= 5 ? 2 : 1)) void wgrad_c3_kernel(Wg
 // conv1: dW[co][ci][ky][kx] = sum_wg slab[wg][ky][co][3kx + ci]            (Cout = C, Cin = 3)
 __global__ __launch_bounds__(256) void c3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nwg, int C,
                                                         int kind, int accumulate) {
-  // 16 lanes per output element split the nwg slabs (fixed assignment + fixed shuffle tree => reproducible)
-  const int total = 9 * C * 27;
-  const int sub = threadIdx.x & 15;
-  for (int i = blockIdx.x * 16 + (threadIdx.x >> 4); i < total; i += gridDim.x * 16) {
-    const int q = i % 27, t = i / 27, ch = t % C, ky = t / C;
-    float s = 0.f;
-    for (int w = sub; w < nwg; w += 16) s += slab[((size_t)(w * 9 + ky) * C + ch) * 32 + q];
-    s += __shfl_xor(s, 8, 16);
-    s += __shfl_xor(s, 4, 16);
-    s += __shfl_xor(s, 2, 16);
-    s += __shfl_xor(s, 1, 16);
-    if (sub == 0) {
-      int co, ci, kx;
+  // Workgroup = 16 float4 items (256 B of one slab row, fully used cache lines) x 16 slab groups: group sg sums slabs
+  // sg, sg+16, ... with independent 16-B loads, the 16 group sums are combined in fixed order through LDS (reproducible).
+  // (The first version gave 16 lanes ONE float of 16 different slabs each: 4 used floats per 64-B line, 2.3 TB/s.)
+  __shared__ f32x4 part[16][16];
+  const int item = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int total4 = 9 * C * 8;                               // float4 items of one slab ([9][C][32] floats)
+  const int i4 = blockIdx.x * 16 + item;
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < total4) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(slab) + i4;
+#pragma unroll 8
+    for (int w = sg; w < nwg; w += 16) t += src[(size_t)w * total4];
+  }
+  part[sg][item] = t;
+  __syncthreads();
+  if (sg == 0 && i4 < total4) {
+#pragma unroll
+    for (int g = 1; g < 16; ++g) t += part[g][item];
+    const int q0 = (i4 & 7) * 4, ch = (i4 >> 3) % C, ky = (i4 >> 3) / C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = q0 + e;
+      if (q >= 27) continue;
+      int co, ci;
+      const int kx = q / 3;
       if (kind == 0) {            // q = 3kx - co + 2  ->  co = 3kx + 2 - q in {0,1,2}
-        kx = q / 3;
         co = 3 * kx + 2 - q;
         ci = ch;
       } else {                    // q = 3kx + ci
-        kx = q / 3;
         ci = q - 3 * kx;
         co = ch;
       }
       const int Cin = kind == 0 ? C : 3;
       float* d = dw + (((size_t)co * Cin + ci) * 9 + ky) * 9 + kx;
-      *d = accumulate ? *d + s : s;
+      *d = accumulate ? *d + t[e] : t[e];
     }
   }
 }
@@ -270,7 +280,7 @@ SST_API int sst_wgrad_c3(const float* big, const float* small, float* slab, floa
   else if (nu <= 7) wgrad_c3_kernel<7><<<nwg, CONV_NT, smem, st>>>(a);
   else wgrad_c3_kernel<9><<<nwg, CONV_NT, smem, st>>>(a);
   SST_LAUNCH_CHECK("wgrad_c3_kernel");
-  c3_reduce_kernel<<<(9 * C * 27 + 15) / 16, 256, 0, sst_stream(stream)>>>(slab, dw, nwg, C, kind, accumulate);
+  c3_reduce_kernel<<<(9 * C * 8 + 15) / 16, 256, 0, sst_stream(stream)>>>(slab, dw, nwg, C, kind, accumulate);
   SST_LAUNCH_CHECK("c3_reduce_kernel");
   return SST_OK;
 }
