@@ -188,10 +188,7 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(R, r0 + rows_per_block);
   if (rl < rowlanes) {
-    for (int64_t r = r0 + rl; r < r1; r += rowlanes) {
-      f32x4 gv = reinterpret_cast<const f32x4*>(g)[r * c4n + cl];
-      if (g2) gv += reinterpret_cast<const f32x4*>(g2)[r * c4n + cl];
-      const f32x4 yv = reinterpret_cast<const f32x4*>(y)[r * c4n + cl];
+    auto accumulate = [&](const f32x4& gv, const f32x4& yv) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float z = fmaf(yv[j], sc[j], sh[j]);
@@ -203,6 +200,25 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
         s0[j] += gz;
         s1[j] += gz * yv[j];
       }
+    };
+    int64_t r = r0 + rl;
+    constexpr int U = 4;             // rows in flight per thread (one row at a time left the kernel latency-bound: 1.3 TB/s)
+    for (; r + (int64_t)(U - 1) * rowlanes < r1; r += (int64_t)U * rowlanes) {
+      f32x4 gv[U], yv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t o = (r + (int64_t)u * rowlanes) * c4n + cl;
+        gv[u] = reinterpret_cast<const f32x4*>(g)[o];
+        yv[u] = reinterpret_cast<const f32x4*>(y)[o];
+        if (g2) gv[u] += reinterpret_cast<const f32x4*>(g2)[o];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accumulate(gv[u], yv[u]);      // same row order as the rolled loop: same sums
+    }
+    for (; r < r1; r += rowlanes) {
+      f32x4 gv = reinterpret_cast<const f32x4*>(g)[r * c4n + cl];
+      if (g2) gv += reinterpret_cast<const f32x4*>(g2)[r * c4n + cl];
+      accumulate(gv, reinterpret_cast<const f32x4*>(y)[r * c4n + cl]);
     }
     float* d = sm + (size_t)rl * 3 * C;
 #pragma unroll
@@ -315,11 +331,25 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
   const int c4n = C >> 2;
   const int64_t total = R * c4n;
   const float slope = slope_p ? slope_p[0] : slope_c;
-  for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  constexpr int U = 4;               // items in flight per thread (loads of a batch issued before the first is used)
+  for (int64_t i0 = blockIdx.x * (int64_t)NT + threadIdx.x; i0 < total; i0 += stride * U) {
+    f32x4 gvs[U], yvs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      const int64_t il = i < total ? i : i0;              // past the end: re-read a valid item, result dropped
+      gvs[u] = reinterpret_cast<const f32x4*>(g)[il];
+      yvs[u] = reinterpret_cast<const f32x4*>(y)[il];
+      if (g2) gvs[u] += reinterpret_cast<const f32x4*>(g2)[il];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int64_t i = i0 + u * stride;
+    if (i >= total) break;
     const int c = (int)(i % c4n) * 4;
-    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
-    if (g2) gv += reinterpret_cast<const f32x4*>(g2)[i];
-    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+    const f32x4 gv = gvs[u];
+    const f32x4 yv = yvs[u];
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -341,6 +371,7 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
       float* d = dy + (((b * (uH >> 1) + (Y >> 1)) * (uW >> 1) + (X >> 1)) * (int64_t)(4 * C)) + 2 * (Y & 1) + (X & 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[4 * (c + j)] = o[j];
+    }
     }
   }
 }
