@@ -139,6 +139,44 @@ __device__ __forceinline__ void conv_fwd_body(const Conv3Args& a, const int bx, 
             kC[j] = a.in_cC[c + j];
           }
       }
+      if (S == 2 && vec_ok && !a.in2) {
+        // Stride 2 (10 patch pixels per thread, LDS-limited to 3 workgroups per CU): batches of 5 pixels with all global loads
+        // of a batch issued before the first is consumed; branch-free (slots outside the image / past NP read the tensor's
+        // first pixel and are zeroed) so that the vmcnt waits stay counted.
+        constexpr int PPT = CONV_NT / 16;
+        constexpr int NIT = (NP + PPT - 1) / PPT;
+        constexpr int UNB = 5;
+        const int nit = (a.dbg & 1) ? 0 : NIT;
+        for (int u0 = 0; u0 < nit; u0 += UNB) {
+          f32x4 v[UNB];
+          bool ok[UNB];
+#pragma unroll
+          for (int u = 0; u < UNB; ++u) {
+            const int p = (tid >> 4) + (u0 + u) * PPT;
+            const int py = p / PW, px = p - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            ok[u] = p < NP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c < a.Cin;
+            const size_t off = ok[u] ? (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + c : (size_t)c4;
+            v[u] = *reinterpret_cast<const f32x4*>(a.x + off);
+          }
+#pragma unroll
+          for (int u = 0; u < UNB; ++u) {
+            const int p = (tid >> 4) + (u0 + u) * PPT;
+            if (p >= NP) continue;
+            f32x4 t = v[u];
+            if (a.in_scale) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) t[j] = fmaf(t[j], sc[j], sh[j]);
+            }
+            if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) t[j] = t[j] > 0.f ? t[j] : t[j] * slope;
+            }
+            if (!ok[u]) t = f32x4{0.f, 0.f, 0.f, 0.f};          // zero padding stays exactly zero
+            *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = t;
+          }
+        }
+      } else
       for (int p = tid >> 4; p < ((a.dbg & 1) ? 0 : NP); p += CONV_NT / 16) {
         const int py = p / PW, px = p - py * PW;
         const int iy = iy0 + py, ix = ix0 + px;
