@@ -282,6 +282,102 @@ __global__ __launch_bounds__(CONV_NT, 5) void conv_s2dgrad_kernel(Conv3Args a, S
   conv_fwd_body<3, 1>(a, blockIdx.x, blockIdx.y);
 }
 
+// Data-gradient of a stride-2 conv, all 4 parity classes of one 8x4 block of class pixels (= a 16x8 block of dX) in ONE
+// workgroup: the classes read the same (8+1) x (4+1) patch of dY, so it is staged once instead of four times, and a
+// workgroup runs 9 (class, tap) x 8 k-steps = 288 MFMAs per 64-channel block of dY instead of 32..128 (the per-class
+// launch above spends most of its time staging).  Plain form only (no fused BatchNorm-backward input / epilogue sums), even
+// H and W (all classes share one nh x nw grid), channels of dY a multiple of 4.
+// K split: wave w takes k-steps {2w, 2w+1} of every (class, tap) - the accumulator of a class is a compile-time index.
+__global__ __launch_bounds__(CONV_NT, 3) void conv_s2dgrad4_kernel(Conv3Args a, S2Classes c) {
+  constexpr int PW = TWO + 1, PH = THO + 1, NP = PW * PH;
+  constexpr int LDS_FLOATS = (NP * LDSC > 4 * 32 * 33) ? NP * LDSC : 4 * 32 * 33;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  __shared__ float sstat[4][3][32];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nh = c.nh[0], nw = c.nw[0];
+  const int tiles_x = (nw + TWO - 1) / TWO, tiles_y = (nh + THO - 1) / THO;
+  const int mt = blockIdx.x;
+  const int b = mt / (tiles_x * tiles_y), rt = mt - b * tiles_x * tiles_y;
+  const int oy0 = (rt / tiles_x) * THO, ox0 = (rt % tiles_x) * TWO;
+  const int nf = blockIdx.y;
+  const int ncb = (a.Cin + CB - 1) / CB;
+  const int a_base = ((li >> 3) * PW + (li & 7)) * LDSC + 4 * lh;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  // the 18 chunks of a wave per channel block: q -> (combo = q / 2, k-step 2*wave + q % 2); combo -> (class, tap)
+  constexpr int CLS_OF[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+  constexpr int TAP_OF[9] = {0, 0, 1, 0, 1, 0, 1, 2, 3};
+  for (int cb = 0; cb < ncb; ++cb) {
+    const int c0 = cb * CB;
+    const int nks = (min(CB, a.Cin - c0) + 7) >> 3;
+    auto load_b = [&](const int q) {
+      const int combo = q >> 1, cls = CLS_OF[combo], tap = TAP_OF[combo];
+      const int KKc = (1 + (cls >> 1)) * (1 + (cls & 1));
+      const int ks = 2 * wave + (q & 1);
+      const float* src = a.wp + c.wp_off[cls] + (((size_t)(nf * ncb + cb) * KKc + tap) * 8 + (ks < nks ? ks : 0)) * 256 + lane * 4;
+      return *reinterpret_cast<const f32x4*>(src);
+    };
+    f32x4 bq[2][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bq[0][i] = load_b(i);             // in flight while the patch is staged
+    if (cb) __syncthreads();
+    {
+      const int c4 = (tid & 15) * 4, ch = c0 + c4;
+      f32x4 v[3];
+      bool ok[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int p = (tid >> 4) + u * 16;
+        const int py = p / PW, px = p - py * PW;
+        const int iy = oy0 + py, ix = ox0 + px;
+        ok[u] = p < NP && iy < a.H && ix < a.W && ch < a.Cin;
+        v[u] = *reinterpret_cast<const f32x4*>(a.x + (ok[u] ? (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + ch : (size_t)c4));
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int p = (tid >> 4) + u * 16;
+        if (p < NP) *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = ok[u] ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      if (g + 1 < 3) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bq[(g + 1) & 1][i] = load_b((g + 1) * 6 + i);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int q = g * 6 + i, combo = q >> 1, cls = CLS_OF[combo], tap = TAP_OF[combo];
+        const int ntx = 1 + (cls & 1), jy = tap / ntx, jx = tap - jy * ntx;
+        const int ks = 2 * wave + (q & 1);
+        if (ks < nks) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(&lds[a_base + (jy * PW + jx) * LDSC + ks * 8]);
+          const f32x4 bv = bq[g & 1][i];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[cls], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const bool tile_ok = oy0 < nh && ox0 < nw;
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    Conv3Args t = a;
+    t.sub_y = cls >> 1;
+    t.sub_x = cls & 1;
+    t.Ho = nh;
+    t.Wo = nw;
+    conv_tile_epilogue(t, lds, sstat, acc[cls], b, oy0, ox0, nf, mt, tile_ok, tid, wave, lane);
+  }
+}
+
 // 3x3 / stride 1 / pad 1 conv with a 3-CHANNEL input and bias (Discriminator.features[0], model.py:32: the image enters the
 // network).  K = 27: an MFMA tile would be 27/64 deep and the general kernel runs this shape at 7 TFLOP/s; the op is bound by
 // writing its 64-channel output (37.7 MB at 96 px, B = 16), so: plain VALU, one workgroup per output row, the 3 input rows in
@@ -753,6 +849,14 @@ static int conv_s2_dgrad_impl(const float* dy, const float* wp, float* dx, int B
       t.Ho = c.nh[cls]; t.Wo = c.nw[cls];
       if (!f && c.tiles[cls] && use_big_tiles(t, 3)) ok = false;
       max_tiles = c.tiles[cls] > max_tiles ? c.tiles[cls] : max_tiles;
+    }
+    static const bool s2d4 = !(getenv("SST_S2DGRAD4") && atoi(getenv("SST_S2DGRAD4")) == 0);
+    if (ok && !f && s2d4 && !(H & 1) && !(W & 1) && !(Cout & 3) && !(Cin & 3)) {
+      a.Ho = c.nh[0]; a.Wo = c.nw[0];
+      dim3 grid((unsigned)c.tiles[0], (Cin + 31) / 32);
+      conv_s2dgrad4_kernel<<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, c);
+      SST_LAUNCH_CHECK("conv_s2dgrad4_kernel");
+      return SST_OK;
     }
     if (ok) {
       dim3 grid((unsigned)max_tiles, (Cin + 31) / 32, 4);
