@@ -28,8 +28,11 @@ def ops():
     return ops
 
 
-@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 13, 9, 8, 16), (2, 12, 12, 128, 128), (1, 6, 6, 64, 32), (1, 7, 10, 64, 64)])
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 13, 9, 8, 16), (2, 12, 12, 128, 128), (1, 6, 6, 64, 32), (1, 7, 10, 64, 64),
+                                  (1, 10, 18, 40, 24), (3, 16, 8, 96, 72), (2, 96, 96, 64, 64)])
 def test_conv_s2_dgrad(ops, case):
+    # even H and W with channel counts that are multiples of 4 take the merged-classes kernel (conv_s2dgrad4_kernel: partial
+    # tiles, partial channel blocks on either side); odd sizes the per-class launch
     B, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(21)
     x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
