@@ -288,6 +288,9 @@ __global__ __launch_bounds__(CONV_NT, 5) void conv_s2dgrad_kernel(Conv3Args a, S
 // launch above spends most of its time staging).  Plain form only (no fused BatchNorm-backward input / epilogue sums), even
 // H and W (all classes share one nh x nw grid), channels of dY a multiple of 4.
 // K split: wave w takes k-steps {2w, 2w+1} of every (class, tap) - the accumulator of a class is a compile-time index.
+// FUSED: the BatchNorm-backward stage around the data-gradient (sst_conv_s2_dgrad_fused): the staged value is
+// dy = cA*gz + cB*y2 + cC with gz = g * act'(y2*in_scale + in_shift), written once to side_out; epilogue sums into epi_partial.
+template <bool FUSED>
 __global__ __launch_bounds__(CONV_NT, 3) void conv_s2dgrad4_kernel(Conv3Args a, S2Classes c) {
   constexpr int PW = TWO + 1, PH = THO + 1, NP = PW * PH;
   constexpr int LDS_FLOATS = (NP * LDSC > 4 * 32 * 33) ? NP * LDSC : 4 * 32 * 33;
@@ -329,7 +332,8 @@ __global__ __launch_bounds__(CONV_NT, 3) void conv_s2dgrad4_kernel(Conv3Args a, 
     if (cb) __syncthreads();
     {
       const int c4 = (tid & 15) * 4, ch = c0 + c4;
-      f32x4 v[3];
+      f32x4 v[3], yv[3];
+      size_t off[3];
       bool ok[3];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
@@ -337,12 +341,47 @@ __global__ __launch_bounds__(CONV_NT, 3) void conv_s2dgrad4_kernel(Conv3Args a, 
         const int py = p / PW, px = p - py * PW;
         const int iy = oy0 + py, ix = ox0 + px;
         ok[u] = p < NP && iy < a.H && ix < a.W && ch < a.Cin;
-        v[u] = *reinterpret_cast<const f32x4*>(a.x + (ok[u] ? (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + ch : (size_t)c4));
+        off[u] = ok[u] ? (((size_t)b * a.H + iy) * a.W + ix) * a.Cin + ch : (size_t)c4;
+        v[u] = *reinterpret_cast<const f32x4*>(a.x + off[u]);
+        if (FUSED) yv[u] = *reinterpret_cast<const f32x4*>(a.in2 + off[u]);
+      }
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      f32x4 kA = {1.f, 1.f, 1.f, 1.f}, kB = {0.f, 0.f, 0.f, 0.f}, kC = {0.f, 0.f, 0.f, 0.f};
+      float slope = 0.f;
+      if (FUSED) {
+        slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
+        if (ch < a.Cin) {                 // Cin % 4 == 0 (checked by the entry point): the quad is in range as a whole
+          if (a.in_scale) {
+            sc = *reinterpret_cast<const f32x4*>(a.in_scale + ch);
+            sh = *reinterpret_cast<const f32x4*>(a.in_shift + ch);
+          }
+          if (a.in_cA) {
+            kA = *reinterpret_cast<const f32x4*>(a.in_cA + ch);
+            kB = *reinterpret_cast<const f32x4*>(a.in_cB + ch);
+            kC = *reinterpret_cast<const f32x4*>(a.in_cC + ch);
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int p = (tid >> 4) + u * 16;
-        if (p < NP) *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = ok[u] ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p >= NP) continue;
+        f32x4 t = v[u];
+        if (FUSED) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float gz = t[j];
+            if (a.in_act == ACT_SLOPE) {
+              const float z = fmaf(yv[u][j], sc[j], sh[j]);
+              gz = z > 0.f ? gz : gz * slope;
+            }
+            t[j] = a.in_cA ? fmaf(kA[j], gz, fmaf(kB[j], yv[u][j], kC[j])) : gz;
+          }
+          // the block's own 8x4 pixels (not the +1 halo row / column) are written once, by the nf == 0 workgroup
+          const int py = p / PW, px = p - py * PW;
+          if (ok[u] && a.side_out && nf == 0 && py < THO && px < TWO) *reinterpret_cast<f32x4*>(a.side_out + off[u]) = t;
+        }
+        *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = ok[u] ? t : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     __syncthreads();
@@ -374,6 +413,10 @@ __global__ __launch_bounds__(CONV_NT, 3) void conv_s2dgrad4_kernel(Conv3Args a, 
     t.sub_x = cls & 1;
     t.Ho = nh;
     t.Wo = nw;
+    t.in2 = nullptr;                   // staging-side fields are not the epilogue's business
+    t.side_out = nullptr;
+    if (FUSED && a.epi_partial) t.epi_partial = a.epi_partial + (size_t)c.tile_base[cls] * 3 * a.Cout;
+    if (!FUSED) t.epi_partial = nullptr;
     conv_tile_epilogue(t, lds, sstat, acc[cls], b, oy0, ox0, nf, mt, tile_ok, tid, wave, lane);
   }
 }
@@ -851,10 +894,13 @@ static int conv_s2_dgrad_impl(const float* dy, const float* wp, float* dx, int B
       max_tiles = c.tiles[cls] > max_tiles ? c.tiles[cls] : max_tiles;
     }
     static const bool s2d4 = !(getenv("SST_S2DGRAD4") && atoi(getenv("SST_S2DGRAD4")) == 0);
-    if (ok && !f && s2d4 && !(H & 1) && !(W & 1) && !(Cout & 3) && !(Cin & 3)) {
+    if (ok && s2d4 && !(H & 1) && !(W & 1) && !(Cout & 3) && !(Cin & 3)) {
       a.Ho = c.nh[0]; a.Wo = c.nw[0];
       dim3 grid((unsigned)c.tiles[0], (Cin + 31) / 32);
-      conv_s2dgrad4_kernel<<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, c);
+      if (f)
+        conv_s2dgrad4_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, c);
+      else
+        conv_s2dgrad4_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, c);
       SST_LAUNCH_CHECK("conv_s2dgrad4_kernel");
       return SST_OK;
     }
