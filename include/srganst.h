@@ -150,6 +150,8 @@ int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B, int H,
 /* one BatchNorm-backward stage around the stride-2 data-gradient (contract of sst_conv_dgrad_fused; g / y2 / dy_out live on the
  * conv's output side [B,Ho,Wo,Cout], dx / epi_y are [B,H,W,Cin]); epi_partial [sst_conv_s2_dgrad_tiles(B,H,W)][3][Cin] */
 int sst_conv_s2_dgrad_tiles(int B, int H, int W);
+/* kernel the two entries above launch for this shape, as rocprofv3 prints it (profiling labels) */
+const char* sst_conv_s2_dgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int fused);
 int sst_conv_s2_dgrad_fused(const float* g, const float* y2, const float* cA, const float* cB, const float* cC,
                             const float* in_scale, const float* in_shift, const float* in_slope, float in_slope_const,
                             int in_act, float* dy_out, const float* wp, float* dx, const float* epi_y,

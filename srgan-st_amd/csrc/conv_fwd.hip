@@ -937,6 +937,15 @@ static int conv_s2_dgrad_impl(const float* dy, const float* wp, float* dx, int B
   return SST_OK;
 }
 
+// Name of the kernel sst_conv_s2_dgrad (fused = 0) / sst_conv_s2_dgrad_fused (fused = 1) launch for this shape (rocprofv3
+// spelling): the merged-classes kernel for even H, W with channel counts that are multiples of 4, else the per-class launch.
+SST_API const char* sst_conv_s2_dgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int fused) {
+  (void)B;
+  const bool off = getenv("SST_S2DGRAD4") && atoi(getenv("SST_S2DGRAD4")) == 0;
+  if (!off && !(H & 1) && !(W & 1) && !(Cout & 3) && !(Cin & 3)) return fused ? "conv_s2dgrad4_kernel<true>" : "conv_s2dgrad4_kernel<false>";
+  return "conv_s2dgrad_kernel";
+}
+
 SST_API int sst_conv_s2_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout,
                               void* stream) {
   return conv_s2_dgrad_impl(dy, wp, dx, B, H, W, Cin, Cout, stream, nullptr);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "sst_conv9_to3_pack": (c_int, [P, P, c_int, P]),
     "sst_conv9_to3_fwd": (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_s2_dgrad_tiles": (c_int, [c_int, c_int, c_int]),
+    "sst_conv_s2_dgrad_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_s2_dgrad_fused": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, P, c_float, c_int, P,
                                         c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_s2_dgrad_packed_floats": (c_int64, [c_int, c_int]),

@@ -403,7 +403,10 @@ def conv_s2_dgrad(dy, wp, H, W, cin):
     dx = _f32(B, H, W, cin, like=dy)
     e0 = _prof_begin()
     check(_abi.lib().sst_conv_s2_dgrad(ptr(dy), ptr(wp), ptr(dx), B, H, W, cin, cout, stream_ptr()), "sst_conv_s2_dgrad")
-    _prof_end(e0, "conv_fwd_kernel<3,1>(s2-dgrad x4)", 2.0 * B * ho * wo * cout * cin * 9)
+    if PROFILE is not None or TRACE is not None:
+        name, flops = _abi.lib().sst_conv_s2_dgrad_kernel_name(B, H, W, cin, cout, 0).decode(), 2.0 * B * ho * wo * cout * cin * 9
+        _prof_end(e0, name, flops)
+        _trace(name, flops, lambda: _abi.lib().sst_conv_s2_dgrad(ptr(dy), ptr(wp), ptr(dx), B, H, W, cin, cout, stream_ptr()), dy, wp, dx)
     return dx
 
 
@@ -421,8 +424,9 @@ def conv_s2_dgrad_fused(g, y2, wp, H, W, cin, cA=None, cB=None, cC=None, in_scal
     e0 = _prof_begin()
     check(_abi.lib().sst_conv_s2_dgrad_fused(*args, stream_ptr()), "sst_conv_s2_dgrad_fused")
     flops = 2.0 * B * ho * wo * cout * cin * 9
-    _prof_end(e0, "conv_s2dgrad_kernel", flops)
-    _trace("conv_s2dgrad_kernel", flops, lambda: _abi.lib().sst_conv_s2_dgrad_fused(*args, stream_ptr()),
+    name = _abi.lib().sst_conv_s2_dgrad_kernel_name(B, H, W, cin, cout, 1).decode() if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: _abi.lib().sst_conv_s2_dgrad_fused(*args, stream_ptr()),
            g, y2, cA, cB, cC, in_scale, in_shift, in_slope, dy, wp, dx, epi_y, epi_scale, epi_shift, epi_slope, partial)
     return dx, dy, partial
 
