@@ -43,7 +43,7 @@ struct WgradArgs {
 
 // VEC: Cin % 4 == 0 and Cout % 4 == 0 (every hot-path layer) - the scalar-tail code is compiled out.
 template <bool VEC>
-__global__ __launch_bounds__(CONV_NT) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(CONV_NT, 4) void conv_wgrad_kernel(WgradArgs a) {   // <= 128 registers incl. the 16 accumulator AGPRs: four workgroups per CU (it sat at 138 = three)
   int chunk = blockIdx.x;
   if (a.jobs) {                       // grouped: fetch this workgroup's layer (workgroup-uniform scalar loads)
     const int job = blockIdx.x / a.nchunk;
