@@ -158,11 +158,10 @@ int sst_conv_s2_dgrad_fused(const float* g, const float* y2, const float* cA, co
                             const float* epi_scale, const float* epi_shift, const float* epi_slope, float epi_slope_const,
                             int epi_act, float* epi_partial, int B, int H, int W, int Cin, int Cout, void* stream);
 
-/* weight gradients of njobs layers of IDENTICAL shape in ONE launch (the 33 trunk-shaped convs of the generator):
- * jobs = device array of {const float* x, *dy; float* slab, *dw; const float* in_scale, *in_shift, *in_slope;
- * float in_slope_const; int in_act;} (64 bytes each). */
-/* writes nwords 64-bit words into device memory with a kernel whose ARGUMENTS carry them (graph-capturable) */
-int sst_fill_table(void* dst, const long long* host_words, int nwords, void* stream);
+/* weight gradients of njobs <= 40 layers of IDENTICAL shape in ONE launch (the 33 trunk-shaped convs of the generator):
+ * jobs = HOST array of {const float* x, *dy; float* slab, *dw; const float* in_scale, *in_shift, *in_slope;
+ * float in_slope_const; int in_act;} (64 bytes each, device pointers inside); the table is handed to the kernels as a
+ * by-value argument, so the call is graph-capturable without any device-side table. */
 int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, int W, int Cin, int Cout, int stride,
                            int ksize, int accumulate, void* stream);
 

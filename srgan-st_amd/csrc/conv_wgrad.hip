@@ -10,6 +10,7 @@
 // Each workgroup writes its partial 64x64 tile to a slab [chunk][tap][Cout][Cin]; wgrad_reduce sums the
 // chunks in fixed order into the reference layout [Cout][Cin][KS][KS]  (no atomics: reproducible).
 #include "conv_common.h"
+#include <cstring>
 #include <cstdlib>
 
 namespace {
@@ -24,8 +25,13 @@ struct WgJob {
   float in_slope_const; int in_act;
 };
 
+// Job table of a grouped launch, passed BY VALUE as a kernel argument (2.5 KB of the 4 KB kernarg segment): no device-side
+// table, hence no table-writing launch in front of every grouped weight gradient (it was a 4.5 us kernel per step).
+constexpr int WG_TAB_MAX = 40;
+struct WgJobTab { WgJob j[WG_TAB_MAX]; };
+
 struct WgradArgs {
-  const WgJob* jobs;       // null: single layer (fields below); else blockIdx.x = job * nchunk + chunk
+  int grouped;             // 0: single layer (fields below); else blockIdx.x = job * nchunk + chunk, jobs in the WgJobTab argument
   int nchunk;
   const float* x;          // [B,H,W,Cin]
   const float* dy;         // [B,Ho,Wo,Cout]
@@ -43,12 +49,12 @@ struct WgradArgs {
 
 // VEC: Cin % 4 == 0 and Cout % 4 == 0 (every hot-path layer) - the scalar-tail code is compiled out.
 template <bool VEC>
-__global__ __launch_bounds__(CONV_NT, 4) void conv_wgrad_kernel(WgradArgs a) {   // <= 128 registers incl. the 16 accumulator AGPRs: four workgroups per CU (it sat at 138 = three)
+__global__ __launch_bounds__(CONV_NT, 4) void conv_wgrad_kernel(WgradArgs a, WgJobTab tab) {   // <= 128 registers incl. the 16 accumulator AGPRs: four workgroups per CU (it sat at 138 = three)
   int chunk = blockIdx.x;
-  if (a.jobs) {                       // grouped: fetch this workgroup's layer (workgroup-uniform scalar loads)
+  if (a.grouped) {                    // grouped: fetch this workgroup's layer (workgroup-uniform scalar loads)
     const int job = blockIdx.x / a.nchunk;
     chunk = blockIdx.x - job * a.nchunk;
-    const WgJob jb = a.jobs[job];
+    const WgJob jb = tab.j[job];
     a.x = jb.x; a.dy = jb.dy; a.slab = jb.slab; a.in_scale = jb.in_scale; a.in_shift = jb.in_shift;
     a.in_slope = jb.in_slope; a.in_slope_const = jb.in_slope_const; a.in_act = jb.in_act;
   }
@@ -217,13 +223,13 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_wgrad_kernel(WgradArgs a) {  
 constexpr int WB_XS = 10, WB_DS = 3;      // max register slots (16 B each) per thread for the X patch / dY tile of one band
 
 template <int XS>
-__global__ __launch_bounds__(CONV_NT, 2) void conv_wgrad_band_kernel(WgradArgs a) {
+__global__ __launch_bounds__(CONV_NT, 2) void conv_wgrad_band_kernel(WgradArgs a, WgJobTab tab) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   int chunk = blockIdx.x;
-  if (a.jobs) {
+  if (a.grouped) {
     const int job = blockIdx.x / a.nchunk;
     chunk = blockIdx.x - job * a.nchunk;
-    const WgJob jb = a.jobs[job];
+    const WgJob jb = tab.j[job];
     a.x = jb.x; a.dy = jb.dy; a.slab = jb.slab; a.in_scale = jb.in_scale; a.in_shift = jb.in_shift;
     a.in_slope = jb.in_slope; a.in_slope_const = jb.in_slope_const; a.in_act = jb.in_act;
   }
@@ -483,10 +489,10 @@ inline WgBandPlan wgrad_band_plan(int B, int H, int W, int Cin, int Cout, int ks
 
 // dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci]     (fixed chunk order: reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunk,
-                                                           int KK, int Cout, int Cin, int accumulate, const WgJob* jobs) {
-  if (jobs) {                          // grouped: blockIdx.y = layer
-    slab = jobs[blockIdx.y].slab;
-    dw = jobs[blockIdx.y].dw;
+                                                           int KK, int Cout, int Cin, int accumulate, int grouped, WgJobTab tab) {
+  if (grouped) {                       // grouped: blockIdx.y = layer
+    slab = tab.j[blockIdx.y].slab;
+    dw = tab.j[blockIdx.y].dw;
   }
   const int64_t per_tap = (int64_t)Cout * Cin, total = per_tap * KK;
   const bool split = accumulate & 2;      // flag bit 1: split variant
@@ -566,22 +572,25 @@ SST_API int sst_conv_wgrad_chunks(int B, int Ho, int Wo, int Cin, int Cout, int 
 
 // slab reduce launch: the split variant (flag bit 1 of `accumulate`) when there are many chunks to sum
 static void launch_wgrad_reduce(const float* slab, float* dw, int nchunk, int KK, int Cout, int Cin, int accumulate,
-                                const WgJob* jobs, int njobs, hipStream_t st) {
+                                const WgJobTab* tab, int njobs, hipStream_t st) {
+  static const WgJobTab no_tab{};
+  const WgJobTab& t = tab ? *tab : no_tab;
+  const int grouped = tab != nullptr;
   const int64_t total = (int64_t)KK * Cout * Cin;
   if ((Cin & 3) == 0 && nchunk >= 8) {
     const int blocks = (int)((total / 4 + 63) / 64);
-    wgrad_reduce_kernel<<<dim3(blocks, njobs), 256, 0, st>>>(slab, dw, nchunk, KK, Cout, Cin, (accumulate & 1) | 2, jobs);
+    wgrad_reduce_kernel<<<dim3(blocks, njobs), 256, 0, st>>>(slab, dw, nchunk, KK, Cout, Cin, (accumulate & 1) | 2, grouped, t);
     return;
   }
   const int64_t items = (Cin & 3) == 0 ? total / 4 : total;
   const int rb = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
-  wgrad_reduce_kernel<<<dim3(rb, njobs), 256, 0, st>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate, jobs);
+  wgrad_reduce_kernel<<<dim3(rb, njobs), 256, 0, st>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate, grouped, t);
 }
 
 static long g_wgrad_band_launches = 0;
 SST_API long sst_debug_wgrad_band_launches(void) { return g_wgrad_band_launches; }   // test hook
 
-static int launch_wgrad_band(WgradArgs& a, const WgBandPlan& pl, int njobs, hipStream_t st) {
+static int launch_wgrad_band(WgradArgs& a, const WgBandPlan& pl, int njobs, hipStream_t st, const WgJobTab& tab) {
   ++g_wgrad_band_launches;
   static bool big_lds_enabled = false;
   if (!big_lds_enabled) {
@@ -596,9 +605,9 @@ static int launch_wgrad_band(WgradArgs& a, const WgBandPlan& pl, int njobs, hipS
   dim3 grid((unsigned)pl.nchunk * njobs, (a.Cout >> 6) * (a.Cin >> 6));
   const int xslots = ((pl.R + 2) * (a.W + 2) * 16 + CONV_NT - 1) / CONV_NT;
   if (xslots <= 7)
-    conv_wgrad_band_kernel<7><<<grid, CONV_NT, pl.lds, st>>>(a);
+    conv_wgrad_band_kernel<7><<<grid, CONV_NT, pl.lds, st>>>(a, tab);
   else
-    conv_wgrad_band_kernel<WB_XS><<<grid, CONV_NT, pl.lds, st>>>(a);
+    conv_wgrad_band_kernel<WB_XS><<<grid, CONV_NT, pl.lds, st>>>(a, tab);
   SST_LAUNCH_CHECK("conv_wgrad_band_kernel");
   return SST_OK;
 }
@@ -631,7 +640,8 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   SST_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize & 1) && ksize <= 9,
               "sst_conv_wgrad: bad shape");
   WgradArgs a;
-  a.jobs = nullptr; a.nchunk = 0;
+  a.grouped = 0; a.nchunk = 0;
+  static const WgJobTab no_tab{};
   a.x = x; a.dy = dy; a.slab = slab; a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
   a.in_slope_const = in_slope_const; a.in_act = in_act;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.KS = ksize; a.pad = ksize / 2;
@@ -649,7 +659,7 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   dim3 grid(nchunk, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, 1);
   if (pl.R) {
-    const int rc = launch_wgrad_band(a, pl, 1, sst_stream(stream));
+    const int rc = launch_wgrad_band(a, pl, 1, sst_stream(stream), no_tab);
     if (rc != SST_OK) return rc;
     nchunk = pl.nchunk;
   } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && !getenv("SST_WGRAD_NO_K3C3")) {
@@ -658,47 +668,28 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
     SST_REQUIRE(lds <= 48 * 1024, "sst_conv_wgrad: image too wide for the 3-channel-input kernel (W=%d)", W);
     wgrad_k3c3_kernel<<<dim3(nchunk, 1), CONV_NT, lds, sst_stream(stream)>>>(x, dy, slab, B, H, W, Cout);
   } else if ((Cin & 3) == 0 && (Cout & 3) == 0)
-    conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+    conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, no_tab);
   else
-    conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+    conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, no_tab);
   SST_LAUNCH_CHECK("conv_wgrad_kernel");
   launch_wgrad_reduce(slab, dw, nchunk, KK, Cout, Cin, accumulate, nullptr, 1, sst_stream(stream));
   SST_LAUNCH_CHECK("wgrad_reduce_kernel");
   return SST_OK;
 }
 
-// Device-side table writer: the words travel as KERNEL ARGUMENTS (by value), so the write is an ordinary
-// stream-ordered, graph-capturable launch - no host-to-device copy (which a hipGraph capture would refuse).
-namespace {
-constexpr int TABLE_WORDS = 448;                      // 3.5 KB of kernel arguments
-struct TableWords { long long v[TABLE_WORDS]; };
-__global__ void fill_table_kernel(long long* dst, TableWords w, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = w.v[i];
-}
-}  // namespace
-
-SST_API int sst_fill_table(void* dst, const long long* host_words, int nwords, void* stream) {
-  SST_REQUIRE(dst && host_words && nwords > 0, "sst_fill_table: bad argument");
-  for (int off = 0; off < nwords; off += TABLE_WORDS) {
-    TableWords w;
-    const int n = nwords - off < TABLE_WORDS ? nwords - off : TABLE_WORDS;
-    for (int i = 0; i < n; ++i) w.v[i] = host_words[off + i];
-    fill_table_kernel<<<1, 256, 0, sst_stream(stream)>>>(reinterpret_cast<long long*>(dst) + off, w, n);
-    SST_LAUNCH_CHECK("fill_table_kernel");
-  }
-  return SST_OK;
-}
-
 // Weight gradients of `njobs` layers of IDENTICAL shape in one launch (+ one grouped slab reduce).
-// jobs: device array of WgJob {x, dy, slab, dw, in_scale, in_shift, in_slope, in_slope_const, in_act} (64 bytes each);
+// jobs: HOST array of WgJob {x, dy, slab, dw, in_scale, in_shift, in_slope, in_slope_const, in_act} (64 bytes each, device
+// pointers inside); it travels to the kernels as a by-value argument, at most WG_TAB_MAX = 40 jobs per call.
 // every job's slab holds sst_conv_wgrad_chunks(...) * k*k*Cout*Cin floats.
 SST_API int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, int W, int Cin, int Cout, int stride, int ksize,
                                    int accumulate, void* stream) {
   static_assert(sizeof(WgJob) == 64, "WgJob layout");
-  SST_REQUIRE(jobs && njobs > 0 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize & 1) &&
-                  ksize <= 9, "sst_conv_wgrad_grouped: bad argument");
+  SST_REQUIRE(jobs && njobs > 0 && njobs <= WG_TAB_MAX && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) &&
+                  (ksize & 1) && ksize <= 9, "sst_conv_wgrad_grouped: bad argument (at most %d jobs per call)", WG_TAB_MAX);
+  WgJobTab tab{};
+  memcpy(tab.j, jobs, (size_t)njobs * sizeof(WgJob));
   WgradArgs a;
-  a.jobs = reinterpret_cast<const WgJob*>(jobs);
+  a.grouped = 1;
   a.x = a.dy = nullptr; a.slab = nullptr; a.in_scale = a.in_shift = a.in_slope = nullptr; a.in_slope_const = 0.f; a.in_act = 0;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.KS = ksize; a.pad = ksize / 2;
   a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
@@ -726,15 +717,15 @@ SST_API int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, in
   dim3 grid((unsigned)nchunk * njobs, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
   if (pl.R) {
-    const int rc = launch_wgrad_band(a, pl, njobs, sst_stream(stream));
+    const int rc = launch_wgrad_band(a, pl, njobs, sst_stream(stream), tab);
     if (rc != SST_OK) return rc;
     nchunk = pl.nchunk;
   } else if ((Cin & 3) == 0 && (Cout & 3) == 0)
-    conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+    conv_wgrad_kernel<true><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, tab);
   else
-    conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a);
+    conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, tab);
   SST_LAUNCH_CHECK("conv_wgrad_kernel (grouped)");
-  launch_wgrad_reduce(nullptr, nullptr, nchunk, KK, Cout, Cin, accumulate, a.jobs, njobs, sst_stream(stream));
+  launch_wgrad_reduce(nullptr, nullptr, nchunk, KK, Cout, Cin, accumulate, &tab, njobs, sst_stream(stream));
   SST_LAUNCH_CHECK("wgrad_reduce_kernel (grouped)");
   return SST_OK;
 }

@@ -50,7 +50,6 @@ SIGNATURES = {
     "sst_conv_wgrad_chunks2": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_wgrad": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, P]),
-    "sst_fill_table": (c_int, [P, POINTER(ctypes.c_longlong), c_int, P]),
     "sst_conv_wgrad_grouped": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_bn_finalize": (c_int, [P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_float, c_float, P]),
     "sst_bn_eval_affine": (c_int, [P, P, P, P, P, P, c_int, c_float, P]),

@@ -795,8 +795,7 @@ def adam_flat(p, g, m, v, lr_dev, steps, beta1, beta2, eps, weight_decay):
 
 class WgradGroup:
     """Collects weight-gradient jobs of identical shape and issues them as ONE launch (+ one grouped slab reduce).
-    The device job table and the slab are cached per (shape, count); pointers are refreshed only when they change
-    (never under hipGraph replay: all tensors are static there)."""
+    The slab is cached per (shape, count); the job table (device pointers of every layer) is a kernel argument."""
     _cache = {}
 
     def __init__(self):
@@ -813,7 +812,9 @@ class WgradGroup:
         for j in self.jobs:
             x, dy, dw, k, s = j[:5]
             groups.setdefault((tuple(x.shape), tuple(dy.shape), k, s), []).append(j)
-        for (xs, dys, k, s), js in groups.items():
+        MAXJ = 40                          # jobs per launch: the table is a kernel argument (csrc/conv_wgrad.hip: WG_TAB_MAX)
+        work = [((xs, dys, k, s), js[i:i + MAXJ]) for (xs, dys, k, s), js in groups.items() for i in range(0, len(js), MAXJ)]
+        for (xs, dys, k, s), js in work:
             B, H, W, cin = xs
             cout = dys[-1]
             if len(js) == 1:
@@ -826,7 +827,7 @@ class WgradGroup:
             key = (dev, xs, dys, k, s, len(js))
             ent = WgradGroup._cache.get(key)
             if ent is None:
-                ent = {"slab": torch.empty(len(js) * per, device=dev, dtype=torch.float32), "table": None, "ptrs": None}
+                ent = {"slab": torch.empty(len(js) * per, device=dev, dtype=torch.float32)}
                 WgradGroup._cache[key] = ent
             slab = ent["slab"]
             rows = []
@@ -834,23 +835,16 @@ class WgradGroup:
                 bits = struct.unpack("<q", struct.pack("<fi", slc, act))[0]
                 rows.append([x.data_ptr(), dy.data_ptr(), slab.data_ptr() + 4 * i * per, dw.data_ptr(), sc.data_ptr() if sc is not None else 0,
                              sh.data_ptr() if sh is not None else 0, sl.data_ptr() if sl is not None else 0, bits])
-            if ent["table"] is None:
-                ent["table"] = torch.empty(len(js) * 8, device=dev, dtype=torch.int64)
-            if ent["ptrs"] != rows or torch.cuda.is_current_stream_capturing():
-                # (re)write the table with a kernel that carries the words as arguments: legal under graph capture, and the
-                # captured node then belongs to the graph (replays rewrite the same static pointers)
-                ent["ptrs"] = rows
-                import ctypes
-                flatw = [w for r in rows for w in r]
-                arr = (ctypes.c_longlong * len(flatw))(*flatw)
-                check(_abi.lib().sst_fill_table(ptr(ent["table"]), arr, len(flatw), stream_ptr()), "sst_fill_table")
+            # the job table travels to the kernels by value (kernel argument): a host array is all that is needed
+            import ctypes
+            flatw = [w for r in rows for w in r]
+            arr = (ctypes.c_longlong * len(flatw))(*flatw)
             e0 = _prof_begin()
-            args = (ptr(ent["table"]), len(js), B, H, W, cin, cout, s, k, 0)
+            args = (ctypes.cast(arr, ctypes.c_void_p), len(js), B, H, W, cin, cout, s, k, 0)
             check(_abi.lib().sst_conv_wgrad_grouped(*args, stream_ptr()), "sst_conv_wgrad_grouped")
             flops = 2.0 * B * dys[1] * dys[2] * cout * cin * k * k * len(js)
             name = (_wgrad_name(B, H, W, cin, cout, k, s, len(js)) + "(grouped)+wgrad_reduce_kernel") if (PROFILE is not None or TRACE is not None) else ""
             _prof_end(e0, name, flops)
-            table = ent["table"]
             _trace(name, flops,
-                   lambda args=args: _abi.lib().sst_conv_wgrad_grouped(*args, stream_ptr()), js, slab, table)
+                   lambda args=args: _abi.lib().sst_conv_wgrad_grouped(*args, stream_ptr()), js, slab, arr)
         self.jobs = []
