@@ -60,6 +60,19 @@ def _criterion_total(sr, gt, criterions, weights, adversarial=None):
     return total, vals
 
 
+def _load_inputs(eng, gt, lr):
+    """The captured steps read the engine's static input buffers eng.gt / eng.lr.  A batch handed in as other tensors is copied
+    into them (device-to-device); a caller that fills the static buffers itself - `eng.gt.copy_(host_batch, non_blocking=True)`
+    returns eng.gt - and passes them back pays no extra copy."""
+    if eng.gt is None:
+        eng.gt, eng.lr = gt.clone(), lr.clone()
+        return
+    if gt is not eng.gt:
+        eng.gt.copy_(gt, non_blocking=True)
+    if lr is not eng.lr:
+        eng.lr.copy_(lr, non_blocking=True)
+
+
 class _GraphedStep:
     """Capture ``fn()`` (which reads the static input buffers) into a hipGraph after a few eager warm-up calls."""
 
@@ -152,11 +165,7 @@ class WarmupEngine:
 
     def step(self, gt, lr):
         """One optimisation step on the batch (gt [B,3,H,W], lr [B,3,H/4,W/4], device tensors)."""
-        if self.gt is None:
-            self.gt, self.lr = gt.clone(), lr.clone()
-        else:
-            self.gt.copy_(gt, non_blocking=True)
-            self.lr.copy_(lr, non_blocking=True)
+        _load_inputs(self, gt, lr)
         self._fb()
         if self.dp:
             sdist.allreduce_module_grads(self.G, self.pg, force=True)
@@ -252,11 +261,7 @@ class TrainEngine:
         self.gt = self.lr = self.sr = None
 
     def step(self, gt, lr):
-        if self.gt is None:
-            self.gt, self.lr = gt.clone(), lr.clone()
-        else:
-            self.gt.copy_(gt, non_blocking=True)
-            self.lr.copy_(lr, non_blocking=True)
+        _load_inputs(self, gt, lr)
         self._g_fb()
         if self.dp:
             sdist.allreduce_module_grads(self.G, self.pg, force=True)

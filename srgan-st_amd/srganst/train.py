@@ -57,9 +57,13 @@ def train(config: Config, train_dataset=None, test_dataset=None, max_steps_per_e
         for batch_num, (gt, lr) in enumerate(train_loader):
             if max_steps_per_epoch is not None and batch_num >= max_steps_per_epoch:
                 break
-            gt = gt.to(device=config.DEVICE, non_blocking=True)
+            # host batch straight into the engine's static input buffers when they exist and fit (copy_ returns the buffer)
+            fits = engine.gt is not None and engine.gt.shape == gt.shape
+            gt = engine.gt.copy_(gt, non_blocking=True) if fits else gt.to(device=config.DEVICE, non_blocking=True)
             if config.KERNEL.LR_ON_DEVICE:
                 lr = device_bicubic(gt, scale=1.0 / config.DATA.UPSCALE_FACTOR)
+            elif fits and engine.lr.shape == lr.shape:
+                lr = engine.lr.copy_(lr, non_blocking=True)
             else:
                 lr = lr.to(device=config.DEVICE, non_blocking=True)
             loss_values, d_now = engine.step(gt, lr)
