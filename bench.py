@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the SRGAN-ST training hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload srresnet|srgan]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload srgan|srresnet|srgan_vgg] [--hr 96|192] [--batch B]
 
-N=1 workload (default): BASELINE.json configs[1] - SRResNet x4, 96 px HR crops, B=16 per GPU,
-pixel(MSE) + structure-tensor/3 loss, one full optimisation step (G fwd, losses, G bwd, Adam).
-`--workload srgan` = configs[2] without the VGG content term (G + D + adversarial + pixel + ST, D updated every step);
-`--workload srgan_vgg` = configs[2] with it (seeded-random VGG19: the ImageNet weights are a network fetch).
+Default workload = BASELINE.json's metric: the "G+D+ST-loss step" (reference train.py:116-164 with D_UPDATE_INTERVAL = 1):
+SRGAN x4, 96 px HR crops, B = 16 per GPU, generator step (adversarial 1e-3 + pixel MSE + structure tensor / 3, D frozen but in
+train mode) followed by the discriminator step on gt and sr.detach(), both with Adam.  `value`, `ms_per_step`, `roofline` and
+`cpu_baseline` all describe THAT step.  The SRResNet step of BASELINE configs[1] (warmup.py:74-96, G only) is measured in the same
+run under the same protocol and reported as the secondary key `srresnet_step`.
+`--workload srgan_vgg` = configs[2] with the VGG19 content term (seeded-random VGG19: the ImageNet weights are a network fetch).
 Prints ONE JSON line (rank 0).  Inputs are synthetic DIV2K-shaped tensors already resident in HBM.
+Exit status: 0 only when every measured leg finished; a stalled or failed leg still prints the line (with an "error" key)
+and then exits 3.
 """
 import argparse
 import json
@@ -24,8 +28,25 @@ import torch  # noqa: E402
 
 G_FWD_MAC_PER_IMG = 1277.67e6      # BASELINE.md section 2 (HR 96)
 D_FWD_MAC_PER_IMG = 884.15e6
+VGG_FWD_MAC_PER_IMG = 3583.18e6
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name -> (description, MACs per image per step as multiples of (G fwd, D fwd, VGG fwd))
+    "srgan": ("srgan_x4_hr96_b16_G+D+ST-loss step: adv+mse+st, D updated every step (train.py:116-164; BASELINE metric)", (3, 8, 0)),
+    "srresnet": ("srresnet_x4_hr96_b16_mse+st (warmup.py:74-96; BASELINE configs[1])", (3, 0, 0)),
+    "srgan_vgg": ("srgan_x4_hr96_b16_adv+vgg(random weights)+mse+st_D-every-step (BASELINE configs[2])", (3, 8, 3)),
+}
+
+
+def workload_name(workload, hr, B):
+    return WORKLOADS[workload][0].replace("hr96", f"hr{hr}").replace("_b16_", f"_b{B}_")
+
+
+def flop_per_image(workload, hr):
+    g, d, v = WORKLOADS[workload][1]
+    return 2.0 * (g * G_FWD_MAC_PER_IMG + d * D_FWD_MAC_PER_IMG + v * VGG_FWD_MAC_PER_IMG) * (hr / 96.0) ** 2
 
 
 def synth_batch(B, hr, device, seed):
@@ -55,53 +76,66 @@ def build_engine(workload, device, use_graph, hr):
     G = Generator(cfg).to(device).train()
     if workload == "srgan_vgg":
         from srganst.loss import ContentLossVGG
-        cfg.add_g_criterion("ContentVGG", ContentLossVGG(cfg), 1.0)     # seeded-random VGG19 (ImageNet weights are a fetch)
+        cfg.add_g_criterion("ContentVGG", ContentLossVGG(cfg, allow_random=True), 1.0)     # seeded-random VGG19 (ImageNet weights are a fetch)
     cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
     cfg.add_g_criterion("ST", StructureTensorLoss(), 1.0 / 3.0)
     cfg.SOLVER.D_UPDATE_INTERVAL = 1
     return TrainEngine(cfg, G, D, use_graph=use_graph), cfg
 
 
+def _replay_time(calls, reps=20):
+    """Seconds for one back-to-back pass over `calls` (relaunch closures), replayed from a hipGraph on the launch stream and
+    bracketed by HIP events on that stream (GPU-bound: no host gaps inside the timed region)."""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for fn, _, _ in calls:
+            fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for fn, _, _ in calls:
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
 def kernel_roofline(workload, device, hr, B):
-    """Live HIP-event timing of the MFMA conv kernels: one eager step records every launch of a kernel family
-    (same pointers, same shapes); each family is then replayed back-to-back from a hipGraph on the launch stream
-    (GPU-bound: no host gaps inside the timed region), bracketed by HIP events.  The family with the largest
-    time share is reported against the fp32 MFMA peak."""
+    """Live HIP-event timing of the step's kernels: one eager step records every launch of a kernel family (same pointers,
+    same shapes); each family is then replayed back-to-back from a hipGraph.  MFMA families are priced against the fp32
+    MFMA peak (algorithmic FLOPs = 2*B*Ho*Wo*Cout*Cin*k*k per launch), HBM-bound families (structure-tensor loss, classifier
+    GEMMs, Adam) against 8 TB/s (algorithmic bytes per launch).  The family with the largest time share
+    is the headline `roofline`."""
     from srganst import ops
     eng, _ = build_engine(workload, device, use_graph=False, hr=hr)
     gt, lr = synth_batch(B, hr, device, 1)
     saved_overlap, ops.OVERLAP = ops.OVERLAP, False
     eng.step(gt, lr)
     torch.cuda.synchronize()
-    ops.TRACE = {}
+    ops.TRACE, ops.TRACE_HBM = {}, {}
     eng.step(gt, lr)
     torch.cuda.synchronize()
-    trace, ops.TRACE = ops.TRACE, None
+    trace, hbm = ops.TRACE, ops.TRACE_HBM
+    ops.TRACE = ops.TRACE_HBM = None
     ops.OVERLAP = saved_overlap
     rows = {}
     for name, calls in trace.items():
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            for fn, _, _ in calls:
-                fn()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for fn, _, _ in calls:
-                fn()
-        g.replay()
-        torch.cuda.synchronize()
-        reps = 20
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / reps                      # seconds for one step's worth of this family
+        t = _replay_time(calls)
         flops = sum(f for _, f, _ in calls)
-        rows[name] = {"launches_per_step": len(calls), "avg_launch_us": t / len(calls) * 1e6, "tflops": flops / t / 1e12,
-                      "ms_per_step": t * 1e3, "flop_per_launch": flops / len(calls)}
+        rows[name] = {"bound": "mfma", "launches_per_step": len(calls), "avg_launch_us": t / len(calls) * 1e6, "tflops": flops / t / 1e12,
+                      "frac": flops / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "ms_per_step": t * 1e3, "flop_per_launch": flops / len(calls)}
+    for name, calls in hbm.items():
+        t = _replay_time(calls)
+        nbytes = sum(f for _, f, _ in calls)
+        rows[name] = {"bound": "hbm", "launches_per_step": len(calls), "avg_launch_us": t / len(calls) * 1e6, "gbs": nbytes / t / 1e9,
+                      "frac": nbytes / t / 1e9 / PEAK_HBM_GBS, "ms_per_step": t * 1e3, "bytes_per_launch": nbytes / len(calls)}
+    eng.close()
     dom = max(rows, key=lambda k: rows[k]["ms_per_step"])
     r = rows[dom]
     traffic = None
@@ -111,21 +145,43 @@ def kernel_roofline(workload, device, hr, B):
             traffic = json.load(open(tf)).get(workload, {}).get(dom)
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": dom, "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": r["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_us": r["avg_launch_us"],
-            "flop_per_launch": r["flop_per_launch"], "launches_per_step": r["launches_per_step"], "kernels": rows}
+    if r["bound"] == "mfma":
+        head = {"bound": "mfma", "kernel": dom, "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": r["frac"], "traffic": traffic, "flop_per_launch": r["flop_per_launch"]}
+    else:
+        head = {"bound": "hbm", "kernel": dom, "achieved": r["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": r["frac"],
+                "traffic": traffic, "bytes_per_launch": r["bytes_per_launch"]}
+    head.update({"avg_launch_us": r["avg_launch_us"], "launches_per_step": r["launches_per_step"], "kernels": rows})
+    return head
 
 
-def cpu_baseline(workload, B, hr, budget_s=20.0):
-    """The CPU oracle (plain-torch restatement of the reference step) timed on the host cores: a bounded sample."""
-    from oracle import model as om
-    from oracle import steps as osteps
-    torch.manual_seed(0)
+def _host_threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 16))     # the 1-GPU box's CPU share is 16 cores; oversubscribing it is far slower
+    return max(1, min(avail, 16))     # the 1-GPU box's CPU share is 16 cores; oversubscribing it is far slower
+
+
+def _time_cpu(fn, gt, lr, budget_s):
+    fn(gt, lr)                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn(gt, lr)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 400:
+            break
+    return n, el
+
+
+def cpu_baseline(workload, B, hr, budget_s=18.0):
+    """The CPU oracle (plain-torch restatement of the reference step) timed on the host cores: a bounded sample of the SAME
+    step as `value`, plus BASELINE configs[0] (SRResNet warm-up step, B = 4, pixel-L1 only: the reference's own CPU case)."""
+    from oracle import model as om
+    from oracle import steps as osteps
+    torch.manual_seed(0)
+    threads = _host_threads()
     torch.set_num_threads(threads)
     if workload == "srresnet":
         tr = osteps.OracleTrainer(om.init_generator_state(), criterions=(("Pixel", 1.0), ("ST", 1.0 / 3.0)))
@@ -144,16 +200,16 @@ def cpu_baseline(workload, B, hr, budget_s=20.0):
                                   d_update_interval=1)
         fn = tr.train_step
     gt, lr = synth_batch(B, hr, "cpu", 1)
-    fn(gt, lr)                                   # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        fn(gt, lr)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 400:
-            break
-    return {"value": B * n / el, "unit": "HR images/s", "cores": threads, "kind": "port",
-            "sample": f"{n} steps of the same B={B} {hr}px step through oracle/ (torch CPU eager, {threads} threads), {el:.1f} s"}
+    n, el = _time_cpu(fn, gt, lr, budget_s)
+    out = {"value": B * n / el, "unit": "HR images/s", "cores": threads, "kind": "port",
+           "sample": f"{n} steps of the same B={B} {hr}px {workload} step through oracle/ (torch CPU eager, {threads} threads), {el:.1f} s"}
+    # BASELINE configs[0]: warmup.py on CPU, 96->24 x4, batch 4, pixel-L1 only
+    tr0 = osteps.OracleTrainer(om.init_generator_state(), criterions=(("Pixel", 1.0),), pixel_kind="l1")
+    gt0, lr0 = synth_batch(4, 96, "cpu", 2)
+    n0, el0 = _time_cpu(tr0.warmup_step, gt0, lr0, 5.0)
+    out["configs0_srresnet_b4_l1"] = {"value": 4 * n0 / el0, "unit": "HR images/s", "cores": threads, "kind": "port",
+                                      "sample": f"{n0} warm-up steps, B=4, 96 px, pixel-L1 only (BASELINE configs[0]), {el0:.1f} s"}
+    return out
 
 
 def timed_steps(eng, gt, lr, steps, warmup, world, device):
@@ -181,37 +237,45 @@ def timed_steps(eng, gt, lr, steps, warmup, world, device):
     return el
 
 
-def full_step_leg(primary, rank, world, device, args, B, steps=40, warmup=6, limit_s=240.0):
-    """The G + D + adversarial + pixel + ST step (`--workload srgan`, D updated every step) under the same timing protocol.
-    Every rank runs a watchdog: if the leg is not done after limit_s, rank 0 prints the primary line and all ranks exit."""
+STALL_EXIT = 3
+
+
+def secondary_leg(primary, workload, rank, world, device, args, B, steps=40, warmup=6, limit_s=240.0):
+    """A second workload under the same timing protocol (the configs[1] SRResNet step next to the headline G+D+ST step).
+    Every rank runs a watchdog: if the leg is not done after limit_s, rank 0 still prints the primary line (with the reason in
+    it), the reason goes to stderr and the process exits NON-ZERO - a stall is a failed run, not a result."""
     import threading
     from srganst import dist as sdist
     done = threading.Event()
+    key = workload + "_step"
 
     def watchdog():
         if not done.wait(limit_s):
+            msg = f"{key}: not finished after {limit_s:.0f} s (stalled GPU leg or collective)"
             if rank == 0:
-                primary["full_srgan_step"] = {"error": f"not finished after {limit_s:.0f} s"}
+                primary[key] = {"error": msg}
                 print(json.dumps(primary), flush=True)
-            os._exit(0)
+            print(f"bench.py: {msg}; exiting {STALL_EXIT}", file=sys.stderr, flush=True)
+            os._exit(STALL_EXIT)
 
     threading.Thread(target=watchdog, daemon=True).start()
     res = None
     try:
-        eng, _ = build_engine("srgan", device, use_graph=not args.no_graph, hr=args.hr)
+        eng, _ = build_engine(workload, device, use_graph=not args.no_graph, hr=args.hr)
         if world > 1:
             sdist.broadcast_module(eng.G)
-            sdist.broadcast_module(eng.D)
+            if hasattr(eng, "D"):
+                sdist.broadcast_module(eng.D)
         gt, lr = synth_batch(B, args.hr, device, seed=100 + rank)
         el = timed_steps(eng, gt, lr, steps, warmup, world, device)
         imgs = B * world * steps / el
-        flop_img = 2 * (3 * G_FWD_MAC_PER_IMG + 8 * D_FWD_MAC_PER_IMG) * (args.hr / 96.0) ** 2
-        res = {"workload": f"srgan_x4_hr{args.hr}_b{B}_adv+mse+st_D-every-step (BASELINE configs[2] minus VGG content)",
-               "value": imgs, "unit": "HR images/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
-               "n_gpus": world, "step_tflops": flop_img * imgs / 1e12}
+        res = {"workload": workload_name(workload, args.hr, B), "value": imgs, "unit": "HR images/s", "ms_per_step": el / steps * 1e3,
+               "steps": steps, "warmup": warmup, "n_gpus": world, "hip_graph": bool(eng.graph_active),
+               "step_tflops": flop_per_image(workload, args.hr) * imgs / 1e12}
         eng.close()
-    except Exception as e:  # noqa: BLE001 - the primary line must survive
+    except Exception as e:  # noqa: BLE001 - the primary line must still be printed; main() then exits non-zero
         res = {"error": f"{type(e).__name__}: {e}"}
+        print(f"bench.py: {key} failed: {res['error']}", file=sys.stderr, flush=True)
     done.set()
     return res
 
@@ -221,7 +285,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="srresnet", choices=["srresnet", "srgan", "srgan_vgg"])
+    ap.add_argument("--workload", default="srgan", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--hr", type=int, default=96)
     ap.add_argument("--no-graph", action="store_true")
@@ -229,7 +293,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="(default) keep weight gradients on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-full-step", action="store_true", help="skip the secondary G+D+ST (srgan) measurement")
+    ap.add_argument("--no-secondary", "--no-full-step", dest="no_secondary", action="store_true",
+                    help="skip the secondary SRResNet (configs[1]) measurement")
     args = ap.parse_args()
 
     from srganst import _abi, dist as sdist, ops as _ops
@@ -252,48 +317,39 @@ def main():
 
     el = timed_steps(eng, gt, lr, args.steps, args.warmup, world, device)
     losses = {k: float(v) for k, v in eng.loss_values.items()}
+    graph_active = bool(eng.graph_active)         # what actually happened, not the flag: a failed capture falls back to eager
+    eng.close()
 
     out = None
+    failed = False
     if rank == 0:
         ms = el / args.steps * 1e3
         imgs = B * world * args.steps / el
-        if args.workload == "srresnet":
-            flop_img = 3 * 2 * G_FWD_MAC_PER_IMG
-            wl = "srresnet_x4_hr96_b16_mse+st (BASELINE configs[1])"
-        elif args.workload == "srgan":
-            flop_img = 2 * (3 * G_FWD_MAC_PER_IMG + 2 * D_FWD_MAC_PER_IMG + 6 * D_FWD_MAC_PER_IMG)
-            wl = "srgan_x4_hr96_b16_adv+mse+st_D-every-step (BASELINE configs[2] minus VGG content)"
-        else:
-            flop_img = 2 * (3 * G_FWD_MAC_PER_IMG + 2 * D_FWD_MAC_PER_IMG + 6 * D_FWD_MAC_PER_IMG + 3 * 3583.18e6)
-            wl = "srgan_x4_hr96_b16_adv+vgg(random weights)+mse+st_D-every-step (BASELINE configs[2])"
-        if args.hr != 96:
-            wl = wl.replace("hr96", f"hr{args.hr}")
-            flop_img *= (args.hr / 96.0) ** 2
-        if B != 16:
-            wl = wl.replace("_b16_", f"_b{B}_")
-        out = {"metric": "HR images/sec (96px x4, B=16/GPU) training step", "value": imgs, "unit": "HR images/s",
+        wl = workload_name(args.workload, args.hr, B)
+        step_kind = {"srgan": "G+D+ST-loss step", "srresnet": "SRResNet G-only mse+ST step", "srgan_vgg": "G+D+VGG+ST-loss step"}[args.workload]
+        out = {"metric": f"HR images/sec ({args.hr}px x4, B={B}/GPU) {step_kind}", "value": imgs, "unit": "HR images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl, "global_batch": B * world, "hr": args.hr, "lr": args.hr // 4,
-                          "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
-                          "step_tflops": flop_img * imgs / 1e12, "losses_last_step": losses}}
-    extra = None
-    if args.workload == "srresnet" and not args.no_full_step:
-        # BASELINE.json's metric text also names the full "G+D+ST-loss step": measured in the same run (same protocol,
-        # fewer steps) and reported beside the configs[1] line.  A watchdog keeps a stuck secondary measurement from
-        # costing the primary line.
-        extra = full_step_leg(out, rank, world, device, args, B)
+                          "parallelism": f"dp{world}", "hip_graph": graph_active, "d_update_interval": 1 if args.workload != "srresnet" else None,
+                          "step_tflops": flop_per_image(args.workload, args.hr) * imgs / 1e12, "losses_last_step": losses}}
+    if args.workload == "srgan" and not args.no_secondary:
+        # BASELINE configs[1] (SRResNet, G only) in the same run, same protocol, fewer steps; at every N, so the driver's
+        # scaling runs also exercise the generator-only gradient all-reduce.
+        extra = secondary_leg(out, "srresnet", rank, world, device, args, B)
+        failed = failed or (extra is not None and "error" in extra)
         if rank == 0:
-            out["full_srgan_step"] = extra
+            out["srresnet_step"] = extra
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = kernel_roofline(args.workload, device, args.hr, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, B, args.hr)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if failed:
+        sys.stdout.flush()
+        os._exit(STALL_EXIT)                       # ranks may have diverged: no closing collective, and the run is a failure
     if world > 1:
-        if extra is not None and "error" in extra:
-            os._exit(0)                            # ranks may have diverged: no closing collective
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

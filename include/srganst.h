@@ -20,6 +20,9 @@ extern "C" {
 const char* sst_last_error(void);
 int sst_version(void);
 const char* sst_arch(void);
+/* forget the HIP runtime's sticky last error (left behind by e.g. a failed stream capture) before going on in eager mode;
+ * returns the pending code (0 = none) */
+int sst_clear_error(void);
 
 /* ---- structure-tensor loss: loss.py:380-413 + utils.py:194-280 (sigma=.5, rho=2 default) -------
  * sr, gt, dsr: NCHW [B,3,H,W].  gS: saved [B,3,H,W].  partials: sst_st_loss_workspace() floats.
@@ -63,6 +66,8 @@ const char* sst_conv_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, i
 long sst_debug_big_tile_launches(void);   /* test hook: launches of the 64x64-tile conv kernel so far */
 long sst_debug_band_launches(void);       /* test hook: launches of the band conv kernel so far */
 long sst_debug_wgrad_band_launches(void); /* test hook: launches of the all-taps weight-gradient kernel so far */
+/* measurement hook (tools/mfma_peak.py): `blocks` workgroups x 4 waves x iters x 4 v_mfma_f32_32x32x2_f32, no memory traffic */
+int sst_debug_mfma_peak(float* out, int blocks, int iters, void* stream);
 int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,
                  const float* in_scale, const float* in_shift, const float* in_slope,
                  float in_slope_const, int in_act, const float* residual, float* stats,

@@ -15,3 +15,40 @@ int sst_set_error(int code, const char* fmt, ...) {
 SST_API const char* sst_last_error(void) { return g_err; }
 SST_API int sst_version(void) { return 100; }  // 0.1.0
 SST_API const char* sst_arch(void) { return "gfx950"; }
+// Forget the runtime's sticky "last error" (hipGetLastError reads AND clears it): a failed stream capture leaves one behind, and
+// the launch check of the next - perfectly good - eager launch would report it.  Returns the code that was pending (0 = none).
+SST_API int sst_clear_error(void) { g_err[0] = 0; return (int)hipGetLastError(); }
+
+// ---- measurement hook (tools/mfma_peak.py): what the chip sustains on the fp32 MFMA the conv kernels are built on, with no
+// memory traffic at all - the clock a long MFMA-dense launch really holds sets the ceiling the conv kernels are read against.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  f32x16_t acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  unsigned ua = threadIdx.x * 2654435761u + blockIdx.x, ub = ua ^ 0x9e3779b9u;
+  for (int i = 0; i < iters; ++i) {
+    // fresh pseudo-random operands in [-0.5, 0.5) every step (an LCG on the mantissa bits): the clock the chip holds depends
+    // on operand toggling, constant operands would flatter it
+    ua = ua * 1664525u + 1013904223u;
+    ub = ub * 22695477u + 1u;
+    const float a = __uint_as_float((ua >> 9) | 0x3f800000u) - 1.5f, b = __uint_as_float((ub >> 9) | 0x3f800000u) - 1.5f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[k], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[k][r];
+  if (s == 12345.678f) out[0] = s;
+}
+SST_API int sst_debug_mfma_peak(float* out, int blocks, int iters, void* stream) {
+  SST_REQUIRE(out && blocks > 0 && iters > 0, "sst_debug_mfma_peak: bad argument");
+  mfma_peak_kernel<0><<<blocks, 256, 0, sst_stream(stream)>>>(out, iters);
+  SST_LAUNCH_CHECK("mfma_peak_kernel");
+  return SST_OK;
+}

@@ -19,6 +19,7 @@ SIGNATURES = {
     "sst_last_error": (c_char_p, []),
     "sst_version": (c_int, []),
     "sst_arch": (c_char_p, []),
+    "sst_clear_error": (c_int, []),
     "sst_st_loss_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64)]),
     "sst_st_loss_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_int, P]),
     "sst_st_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_float, c_float, P]),
@@ -32,6 +33,7 @@ SIGNATURES = {
                             ctypes.c_double, P]),
     "sst_debug_band_launches": (ctypes.c_long, []),
     "sst_debug_wgrad_band_launches": (ctypes.c_long, []),
+    "sst_debug_mfma_peak": (c_int, [P, c_int, c_int, P]),
     "sst_conv_mtiles": (c_int, [c_int, c_int, c_int]),
     "sst_conv_stat_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_fwd": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_int,

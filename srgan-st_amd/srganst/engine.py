@@ -76,13 +76,19 @@ def _load_inputs(eng, gt, lr):
 class _GraphedStep:
     """Capture ``fn()`` (which reads the static input buffers) into a hipGraph after a few eager warm-up calls."""
 
-    def __init__(self, fn, warmup_calls=2, enabled=True):
+    def __init__(self, fn, warmup_calls=2, enabled=True, on_fail=None):
         self.fn = fn
         self.graph = None
         self.enabled = enabled
         self.calls = 0
         self.warmup_calls = warmup_calls
         self.out = None
+        self.on_fail = on_fail      # called once when a capture fails: the owner drops EVERY graph of the engine (see _drop_graphs)
+
+    def drop(self):
+        """Back to eager for good (a sibling step's capture failed: graphs bake in each other's static tensors)."""
+        self.graph = None
+        self.enabled = False
 
     def __call__(self):
         if not self.enabled:
@@ -105,9 +111,14 @@ class _GraphedStep:
                 self.graph = g
             except Exception as e:  # keep training (eager) rather than die: a step is still the same kernels
                 import sys
-                print(f"[srganst] hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode", file=sys.stderr)
+                print(f"[srganst] hipGraph capture failed ({type(e).__name__}: {e}); the whole engine continues in eager mode",
+                      file=sys.stderr)
                 torch.cuda.synchronize()
-                self.enabled = False
+                from . import _abi
+                _abi.lib().sst_clear_error()       # the failed capture leaves a sticky runtime error: the next launch check would trip on it
+                self.drop()
+                if self.on_fail is not None:
+                    self.on_fail()
                 return self.fn()
         self.graph.replay()
         return self.out
@@ -133,11 +144,24 @@ class WarmupEngine:
         self.sr = None
         self.dp = self.world > 1 or force_dp     # force_dp: run the split-graph + collective path even with one rank (tests)
         if self.dp:             # collective stays outside the graph: [fwd+bwd graph] -> all-reduce -> [optimizer]
-            self._fb = _GraphedStep(self._fwd_bwd, enabled=use_graph)
-            self._op = _GraphedStep(self._opt_step, enabled=use_graph)
+            self._fb = _GraphedStep(self._fwd_bwd, enabled=use_graph, on_fail=self._drop_graphs)
+            self._op = _GraphedStep(self._opt_step, enabled=use_graph, on_fail=self._drop_graphs)
         else:
-            self._fb = _GraphedStep(self._full_step, enabled=use_graph)
+            self._fb = _GraphedStep(self._full_step, enabled=use_graph, on_fail=self._drop_graphs)
             self._op = None
+
+    def _steps(self):
+        return [s for s in (self._fb, self._op) if s is not None]
+
+    def _drop_graphs(self):
+        for s in self._steps():
+            s.drop()
+
+    @property
+    def graph_active(self):
+        """True when every part of the step is replayed from a captured hipGraph (False before capture and after a fallback)."""
+        st = self._steps()
+        return bool(st) and all(s.graph is not None for s in st)
 
     # -- pieces
     def _fwd_bwd(self):
@@ -201,12 +225,28 @@ class TrainEngine:
         # backward passes of the discriminator step (disc_graph._packs): this engine owns every update of D's weights
         self.D.__dict__["_packs_managed"] = True
         self.D.__dict__["_packs_fresh"] = False
+        # A captured graph bakes in the tensors that exist at capture time (D's graph reads the generator graph's static `sr`):
+        # a mixed eager / graph state would replay on stale buffers, so ONE failed capture sends the whole engine back to eager.
+        f = self._drop_graphs
         if self.dp:
-            self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g), _GraphedStep(self.g_opt.step, enabled=g)
-            self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g), _GraphedStep(self._d_step, enabled=g)
+            self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self.g_opt.step, enabled=g, on_fail=f)
+            self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self._d_step, enabled=g, on_fail=f)
         else:
-            self._g_fb, self._g_op = _GraphedStep(self._g_full, enabled=g), None
-            self._d_fb, self._d_op = _GraphedStep(self._d_full, enabled=g), None
+            self._g_fb, self._g_op = _GraphedStep(self._g_full, enabled=g, on_fail=f), None
+            self._d_fb, self._d_op = _GraphedStep(self._d_full, enabled=g, on_fail=f), None
+
+    def _steps(self):
+        return [s for s in (self._g_fb, self._g_op, self._d_fb, self._d_op) if s is not None]
+
+    def _drop_graphs(self):
+        for s in self._steps():
+            s.drop()
+
+    @property
+    def graph_active(self):
+        """True when every part of the iteration is replayed from a captured hipGraph."""
+        st = self._steps()
+        return bool(st) and all(s.graph is not None for s in st)
 
     # -- generator half: train.py:125-144
     def _g_fwd_bwd(self):

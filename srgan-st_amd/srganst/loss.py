@@ -35,9 +35,12 @@ class _StLossFn(torch.autograd.Function):
             ws["counter"] = torch.zeros(1, device=x.device, dtype=torch.int32)
         gS = torch.empty_like(x)
         loss = torch.empty((), device=x.device, dtype=torch.float32)
-        _abi.check(lib.sst_st_loss_fwd(_abi.ptr(x), _abi.ptr(gt), _abi.ptr(loss), _abi.ptr(gS), _abi.ptr(ws["partials"]),
-                                       _abi.ptr(ws["counter"]), B, H, W, sigma, rho, int(normalize), _abi.stream_ptr()),
-                   "sst_st_loss_fwd")
+        from . import ops
+        args = (_abi.ptr(x), _abi.ptr(gt), _abi.ptr(loss), _abi.ptr(gS), _abi.ptr(ws["partials"]), _abi.ptr(ws["counter"]), B, H, W,
+                sigma, rho, int(normalize))
+        _abi.check(lib.sst_st_loss_fwd(*args, _abi.stream_ptr()), "sst_st_loss_fwd")
+        # algorithmic bytes: forward reads sr + gt, backward writes d(sr): 3 x 3*H*W*4 B per image in all
+        ops._trace_hbm("st_loss_fwd_kernel", 2.0 * x.numel() * 4, lambda: lib.sst_st_loss_fwd(*args, _abi.stream_ptr()), x, gt, loss, gS, ws)
         ctx.save_for_backward(x, gS)
         ctx.cfg = (sigma, rho)
         return loss
@@ -153,8 +156,10 @@ class _CriterionSumFn(torch.autograd.Function):
         dsr = torch.empty_like(sr)
         for i, (t, w) in enumerate(zip(ctx.terms, ctx.weights)):
             if isinstance(t, StructureTensorLoss):
-                _abi.check(_abi.lib().sst_st_loss_bwd(_abi.ptr(sr), _abi.ptr(ctx.gS[i]), _abi.ptr(dsr), _abi.ptr(g), w, int(i > 0), B, H, W,
-                                                      float(t.sigma), float(t.rho), _abi.stream_ptr()), "sst_st_loss_bwd")
+                bargs = (_abi.ptr(sr), _abi.ptr(ctx.gS[i]), _abi.ptr(dsr), _abi.ptr(g), w, int(i > 0), B, H, W, float(t.sigma), float(t.rho))
+                _abi.check(_abi.lib().sst_st_loss_bwd(*bargs, _abi.stream_ptr()), "sst_st_loss_bwd")
+                ops._trace_hbm("st_loss_bwd_kernel", 1.0 * sr.numel() * 4, lambda bargs=bargs: _abi.lib().sst_st_loss_bwd(*bargs, _abi.stream_ptr()),
+                               sr, ctx.gS[i], dsr, g)
             else:
                 ops.pixel_loss_bwd(sr, gt, 0 if isinstance(t, MSELoss) else 1, scale_dev=g, scale_host=w, out=dsr, accumulate=i > 0)
         return dsr, None, None, None, None

@@ -33,6 +33,16 @@ def _trace(name, flops, fn, *keep):
         TRACE.setdefault(name, []).append((fn, flops, keep))
 
 
+# --- the same for the HBM-bound kernels (structure-tensor loss, classifier GEMMs, Adam): name -> [(relaunch closure, ALGORITHMIC
+# bytes of the launch, keep-alive)]
+TRACE_HBM = None
+
+
+def _trace_hbm(name, nbytes, fn, *keep):
+    if TRACE_HBM is not None:
+        TRACE_HBM.setdefault(name, []).append((fn, float(nbytes), keep))
+
+
 def _prof_begin():
     if PROFILE is None:
         return None
@@ -436,7 +446,9 @@ def linear_fwd(x, w, bias):
     N = w.shape[0]
     y = _f32(M, N, like=x)
     slab = _f32(_abi.lib().sst_linear_ksplit(M, N, K) * M * N, like=x)
-    check(_abi.lib().sst_linear_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), ptr(slab), M, N, K, stream_ptr()), "sst_linear_fwd")
+    args = (ptr(x), ptr(w), ptr(bias), ptr(y), ptr(slab), M, N, K)
+    check(_abi.lib().sst_linear_fwd(*args, stream_ptr()), "sst_linear_fwd")
+    _trace_hbm("linear_fwd_kernel", 4.0 * (N * K + M * K + M * N), lambda: _abi.lib().sst_linear_fwd(*args, stream_ptr()), x, w, bias, y, slab)
     return y
 
 
@@ -446,15 +458,19 @@ def linear_dgrad(dy, w, nhwc=None):
     K = w.shape[1]
     dx = _f32(M, K, like=dy)
     c, hw = nhwc if nhwc else (0, 0)
-    check(_abi.lib().sst_linear_dgrad(ptr(dy), ptr(w), ptr(dx), M, N, K, c, hw, stream_ptr()), "sst_linear_dgrad")
+    args = (ptr(dy), ptr(w), ptr(dx), M, N, K, c, hw)
+    check(_abi.lib().sst_linear_dgrad(*args, stream_ptr()), "sst_linear_dgrad")
+    _trace_hbm("linear_dgrad_kernel", 4.0 * (N * K + M * K + M * N), lambda: _abi.lib().sst_linear_dgrad(*args, stream_ptr()), dy, w, dx)
     return dx
 
 
 def linear_wgrad(dy, x, dw, db=None, accumulate=False):
     M, N = dy.shape
     K = x.shape[1]
-    check(_abi.lib().sst_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), M, N, K, int(accumulate), stream_ptr()),
-          "sst_linear_wgrad")
+    args = (ptr(dy), ptr(x), ptr(dw), ptr(db), M, N, K, int(accumulate))
+    check(_abi.lib().sst_linear_wgrad(*args, stream_ptr()), "sst_linear_wgrad")
+    _trace_hbm("linear_wgrad_kernel", 4.0 * (N * K * (2 if accumulate else 1) + M * K + M * N),
+               lambda: _abi.lib().sst_linear_wgrad(*args, stream_ptr()), dy, x, dw, db)
 
 
 def head_fwd(h, w, b, slope):
@@ -789,8 +805,10 @@ def flatten_params(module):
 
 def adam_flat(p, g, m, v, lr_dev, steps, beta1, beta2, eps, weight_decay):
     assert p.numel() == g.numel() == m.numel() == v.numel() and p.numel() % 4 == 0
-    check(_abi.lib().sst_adam_flat(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(lr_dev), ptr(steps), steps.numel(),
-                                   float(beta1), float(beta2), float(eps), float(weight_decay), stream_ptr()), "sst_adam_flat")
+    args = (ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(lr_dev), ptr(steps), steps.numel(), float(beta1), float(beta2), float(eps),
+            float(weight_decay))
+    check(_abi.lib().sst_adam_flat(*args, stream_ptr()), "sst_adam_flat")
+    _trace_hbm("adam_flat_kernel", 28.0 * p.numel(), lambda: _abi.lib().sst_adam_flat(*args, stream_ptr()), p, g, m, v, lr_dev, steps)
 
 
 class WgradGroup:

@@ -114,8 +114,16 @@ class _VggFn(torch.autograd.Function):
 
 
 class ContentLossVGG(nn.Module):
-    def __init__(self, config, criterion: str = "mse", weights: str | None = None, seed: int = 0) -> None:
+    def __init__(self, config, criterion: str = "mse", weights: str | None = None, seed: int = 0, allow_random: bool = False) -> None:
+        """weights: path of a torchvision-format VGG19 state dict (keys ``features.{i}.weight|bias``; what the reference's
+        ``models.vgg19(weights=IMAGENET1K_V1)`` holds, loss.py:46).  The ImageNet weights are a network fetch, so there is no
+        default: without `weights` the constructor refuses unless the caller opts in to a seeded-random network with
+        allow_random=True (throughput benchmarks and parity tests only - a perceptual term against random features trains
+        nothing meaningful)."""
         super().__init__()
+        if not weights and not allow_random:
+            raise ValueError("ContentLossVGG: pass weights=<torchvision VGG19 state dict> (reference: IMAGENET1K_V1, loss.py:46) or "
+                             "allow_random=True for a seeded-random VGG19 (benchmarks / tests only)")
         if criterion == "l1":
             self.mode = 1
         elif criterion in ("l2", "mse"):
@@ -142,7 +150,13 @@ class ContentLossVGG(nn.Module):
                     m.bias.zero_()
         if weights:
             sd = torch.load(weights, map_location="cpu", weights_only=True)
-            self.load_state_dict({k: v for k, v in sd.items() if k.startswith("features.")}, strict=False)
+            own = self.state_dict()
+            missing = [k for k in own if k.startswith("features.") and k not in sd]
+            bad = [k for k in own if k in sd and tuple(sd[k].shape) != tuple(own[k].shape)]
+            if missing or bad:      # a wrong / partial / renamed state dict must not silently leave random layers behind
+                raise ValueError(f"ContentLossVGG: {weights} is not a VGG19 `features` state dict: missing {missing[:4]}"
+                                 f"{'...' if len(missing) > 4 else ''}, shape mismatch {bad[:4]}")
+            self.load_state_dict({k: sd[k] for k in own if k.startswith("features.")}, strict=False)
         for p in self.parameters():
             p.requires_grad = False
         self.eval()

@@ -280,3 +280,49 @@ def test_train_engine_pack_reuse_equals_repacking(interval):
     for k in d1:
         assert torch.equal(d1[k], d2[k]), k
     assert l1 == l2
+
+
+@pytest.mark.parametrize("fail", ["g", "d"])
+def test_train_engine_capture_failure_drops_every_graph(fail):
+    """A hipGraph bakes in the tensors alive at capture time (D's graph reads the generator graph's static `sr`), so a mixed
+    eager / graph engine would replay on stale buffers.  Force the capture of ONE half to fail (an illegal synchronize while
+    capturing): the whole engine must fall back to eager - graph_active False, no graph kept - and the run must stay
+    bit-identical to an all-eager run."""
+    from srganst.engine import TrainEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+
+    def run(use_graph, sabotage):
+        cfg = make_cfg(16, 2, 8)
+        torch.manual_seed(1)
+        D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
+        cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+        cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+        cfg.SOLVER.D_UPDATE_INTERVAL = 1
+        eng = TrainEngine(cfg, G, D, use_graph=use_graph, adam_capturable=True)
+        if sabotage:
+            step = eng._g_fb if sabotage == "g" else eng._d_fb
+            inner = step.fn
+
+            def fn():
+                if torch.cuda.is_current_stream_capturing():
+                    torch.cuda.synchronize()           # not allowed under capture: the capture fails
+                return inner()
+            step.fn = fn
+        gen = torch.Generator().manual_seed(2)
+        for _ in range(6):
+            eng.step(torch.rand(4, 3, 96, 96, generator=gen).cuda(), torch.rand(4, 3, 24, 24, generator=gen).cuda())
+        torch.cuda.synchronize()
+        return eng, G.state_dict(), D.state_dict(), {k: v.item() for k, v in eng.loss_values.items()}
+
+    e1, g1, d1, l1 = run(False, None)
+    e2, g2, d2, l2 = run(True, fail)
+    assert not e1.graph_active and not e2.graph_active
+    assert all(s.graph is None and not s.enabled for s in e2._steps())
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    for k in d1:
+        assert torch.equal(d1[k], d2[k]), k
+    assert l1 == l2
+    e3 = run(True, None)[0]
+    assert e3.graph_active

@@ -34,7 +34,7 @@ def test_content_loss_vgg_vs_oracle():
     from srganst.config import Config
     from srganst.vgg_loss import ContentLossVGG
     cfg = Config()
-    crit = ContentLossVGG(cfg, seed=7)
+    crit = ContentLossVGG(cfg, seed=7, allow_random=True)
     sd = {k: v.detach().cpu() for k, v in crit.state_dict().items() if k.startswith("features.")}
     ref_sd = ovgg.init_vgg_state(seed=7)
     for k in ref_sd:
@@ -52,3 +52,43 @@ def test_content_loss_vgg_vs_oracle():
     # d(loss)/d(sr) runs back through 16 ReLU layers with random weights: in fp32 a few ReLU masks flip against the fp64 oracle,
     # which moves the norm-wise error between 1.9e-3 and 2.4e-3 depending on the summation order of the first conv
     assert rel_err(xg.grad.cpu() * 0.5, x64.grad) < 4e-3
+
+
+def test_content_loss_vgg_weight_file_round_trip(tmp_path):
+    """The reference always loads torchvision's IMAGENET1K_V1 VGG19 (loss.py:46) - a network fetch, unavailable here, so the
+    loader is exercised with a synthetic state dict in torchvision's format (keys features.{i}.weight|bias over the 16 convs +
+    classifier.* that must be ignored): the loaded network must be exactly the one in the file; no-weights construction must
+    refuse unless allow_random; a partial / renamed / wrong-shape state dict must raise instead of leaving random layers."""
+    from oracle import vgg as ovgg
+    from srganst.config import Config
+    from srganst.vgg_loss import ContentLossVGG
+    cfg = Config()
+    with pytest.raises(ValueError):
+        ContentLossVGG(cfg)
+    sd = dict(ovgg.init_vgg_state(seed=123))
+    sd["classifier.0.weight"] = torch.zeros(8, 8)            # torchvision's file also carries the classifier: ignored
+    path = tmp_path / "vgg19.pth"
+    torch.save(sd, path)
+    crit = ContentLossVGG(cfg, weights=str(path), seed=7)
+    got = crit.state_dict()
+    for k, v in sd.items():
+        if k.startswith("features."):
+            assert torch.equal(got[k].cpu(), v), k
+    g = torch.Generator().manual_seed(9)
+    gt = torch.rand(1, 3, 96, 96, generator=g)
+    x = (gt + 0.1 * torch.randn(1, 3, 96, 96, generator=g)).clamp(0, 1)
+    ref = ovgg.content_loss({k: v for k, v in sd.items() if k.startswith("features.")}, x.double(), gt.double(), cfg.MODEL.G_LOSS.VGG19_LAYERS)
+    assert abs(crit(x.cuda(), gt.cuda()).item() - ref.item()) < 1e-3 * abs(ref.item())
+    partial = {k: v for k, v in sd.items() if not k.startswith("features.28")}
+    torch.save(partial, path)
+    with pytest.raises(ValueError):
+        ContentLossVGG(cfg, weights=str(path))
+    renamed = {"module." + k: v for k, v in sd.items()}
+    torch.save(renamed, path)
+    with pytest.raises(ValueError):
+        ContentLossVGG(cfg, weights=str(path))
+    wrong = dict(sd)
+    wrong["features.0.weight"] = torch.zeros(64, 3, 5, 5)
+    torch.save(wrong, path)
+    with pytest.raises(ValueError):
+        ContentLossVGG(cfg, weights=str(path))
