@@ -102,17 +102,24 @@ class _GraphedStep:
                     out = self.fn()
                 torch.cuda.current_stream().wait_stream(s)
                 return out
+            launch_stream = torch.cuda.current_stream()
             try:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: calls made by OTHER threads during capture (e.g. the RCCL watchdog polling its events)
                 # must not invalidate it
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                # a capture stream of its own: torch's shared default capture stream would stay dead for every later capture
+                # of the process once ONE capture on it has been invalidated
+                with torch.cuda.graph(g, stream=torch.cuda.Stream(), capture_error_mode="thread_local"):
                     self.out = self.fn()
                 self.graph = g
             except Exception as e:  # keep training (eager) rather than die: a step is still the same kernels
                 import sys
                 print(f"[srganst] hipGraph capture failed ({type(e).__name__}: {e}); the whole engine continues in eager mode",
                       file=sys.stderr)
+                # torch.cuda.graph.__exit__ raises from capture_end() BEFORE it leaves its stream context: the current stream
+                # would stay the dead (invalidated) capture stream, on which every later launch fails
+                torch.cuda.set_stream(launch_stream)
+                g = None
                 torch.cuda.synchronize()
                 from . import _abi
                 _abi.lib().sst_clear_error()       # the failed capture leaves a sticky runtime error: the next launch check would trip on it

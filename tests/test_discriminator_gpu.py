@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import assert_fp64_truth, oracle_grads, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -117,6 +117,7 @@ def test_discriminator_full_seed0(golden):
     D = Discriminator(make_cfg())
     assert sum(p.numel() for p in D.parameters()) == 23563649            # reference model.py:194
     assert torch.equal(D.state_dict()["features.0.weight"], T(g["w/features.0.weight"]))
+    sd0 = {k: v.clone() for k, v in D.state_dict().items()}
     D.cuda().train()
     x = T(g["x"]).cuda().requires_grad_(True)
     logit = D(x)
@@ -124,16 +125,28 @@ def test_discriminator_full_seed0(golden):
     loss = BCEWithLogitsLoss()(logit, torch.full([2, 1], 0.9).cuda())
     assert abs(loss.item() - g["loss"].item()) < 1e-4
     loss.backward()
-    assert rel_err(x.grad.cpu(), g["dx"]) < 5e-3
-    norms = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
-    for k, v in D.named_parameters():
-        assert abs(v.grad.norm().item() - norms[k]) <= 5e-3 * norms[k] + 1e-9, k
+    # gradients: fp64-truth criterion (conftest.assert_fp64_truth): truth = the oracle in fp64 on the same weights / input; the
+    # fp32 side of the bound is the REFERENCE's own fp32 gradient where the fixture stores it, the oracle's fp32 run elsewhere
+    from oracle import model as om
+
+    def fl(sdx, x_):
+        lg = om.discriminator_forward(sdx, x_, True, {})
+        return F.binary_cross_entropy_with_logits(lg, torch.full_like(lg, 0.9))
+    ins = ((T(g["x"]), True),)
+    _, g32, (dx32,), _ = oracle_grads(fl, sd0, torch.float32, ins)
+    _, g64, (dx64,), _ = oracle_grads(fl, sd0, torch.float64, ins)
+    assert_fp64_truth("dx", x.grad.cpu(), T(g["dx"]), dx64)
     named = dict(D.named_parameters())
+    report = []
+    for k, v in named.items():
+        ref32 = T(g["g/" + k]) if ("g/" + k) in g.files else g32[k]
+        assert_fp64_truth(k, v.grad.cpu(), ref32, g64[k], report)
     for f in g.files:
-        if f.startswith("g/") and "#" not in f:
-            assert rel_err(named[f[2:]].grad.cpu(), g[f]) < 5e-3, f
-        elif f.startswith("g/") and f.endswith("#head4"):
-            assert rel_err(named[f[2:-6]].grad[:4].cpu(), g[f]) < 5e-3, f
+        if f.startswith("g/") and f.endswith("#head4"):
+            k = f[2:-6]
+            assert_fp64_truth(f, named[k].grad[:4].cpu(), T(g[f]), g64[k][:4])
+    worst = max(report, key=lambda r: r[1])
+    print(f"worst param-grad error vs fp64: {worst[0]} {worst[1]:.2e} (oracle fp32: {worst[2]:.2e})")
 
 
 def test_gan_iteration_small_golden(golden):
@@ -150,6 +163,8 @@ def test_gan_iteration_small_golden(golden):
         key = "d_state0/" + k
         if key in g.files:
             assert torch.equal(v, T(g[key])), k
+    d_state0 = {k: v.clone() for k, v in D.state_dict().items()}
+    g_state0 = {k: v.clone() for k, v in G.state_dict().items()}
     D.cuda().train()
     G.cuda().train()
     cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
@@ -163,12 +178,24 @@ def test_gan_iteration_small_golden(golden):
     assert abs(d_loss.item() - g["d_loss"].item()) < 1e-4
     assert torch.allclose(eng.pred_gt.cpu(), T(g["pred_gt"]), rtol=1e-3, atol=1e-4)
     assert torch.allclose(eng.pred_sr.cpu(), T(g["pred_sr"]), rtol=1e-3, atol=1e-4)
+    # D's gradients of the discriminator step: fp64-truth criterion.  Truth = the oracle iteration (oracle/steps.py, pinned to the
+    # reference's iteration by tests/test_oracle_golden.py) run in fp64 from the same initial states; the fp32 side of the bound is
+    # the REFERENCE's stored gradient where the fixture has it in full, the oracle's fp32 run elsewhere.
+    from oracle import steps as osteps
+
+    def oracle_iter(dtype):
+        tr = osteps.OracleTrainer({k: v.to(dtype) if v.is_floating_point() else v for k, v in g_state0.items()},
+                                  {k: v.to(dtype) if v.is_floating_point() else v for k, v in d_state0.items()},
+                                  criterions=(("Adversarial", 0.001), ("Pixel", 1.0), ("ST", 1.0 / 3.0)), d_update_interval=1)
+        tr.train_step(T(g["gt"]).to(dtype), T(g["lr"]).to(dtype))
+        return tr.d_grads()
+    d32, d64 = oracle_iter(torch.float32), oracle_iter(torch.float64)
     for n, p in D.named_parameters():
         key = "d_grad/" + n
-        if key in g.files:
-            assert rel_err(p.grad.cpu(), g[key]) < 5e-3, n
-        else:
-            assert abs(p.grad.double().norm().item() - g[key + "#norm"].item()) < 5e-3 * g[key + "#norm"].item(), n
+        assert_fp64_truth(n, p.grad.cpu(), T(g[key]) if key in g.files else d32[n], d64[n])
+        if key not in g.files:
+            nrm = g[key + "#norm"].item()
+            assert abs(nrm - d64[n].norm().item()) <= max(1e-3, 3 * rel_err(d32[n], d64[n])) * d64[n].norm().item(), n
     sd = D.state_dict()
     for k in sd:
         key = "d_state1/" + k
@@ -206,6 +233,7 @@ def test_train_engine_graph_equals_eager():
             lr = torch.rand(4, 3, 24, 24, generator=gen).cuda()
             eng.step(gt, lr)
         torch.cuda.synchronize()
+        assert eng.graph_active == use_graph          # the graph run really replays captured graphs
         return G.state_dict(), D.state_dict(), {k: v.item() for k, v in eng.loss_values.items()}
 
     g1, d1, l1 = run(False)
@@ -232,20 +260,21 @@ def test_discriminator_hr192_vs_oracle():
     gen = torch.Generator().manual_seed(18)
     x = torch.rand(2, 3, 192, 192, generator=gen)
     sd = {k: v.clone() for k, v in D.state_dict().items()}
-    for k in om.param_keys(sd):
-        sd[k].requires_grad_(True)
-    xr = x.clone().requires_grad_(True)
-    logit_ref = om.discriminator_forward(sd, xr, True, {})
     target = torch.full([2, 1], 0.9)
-    F.binary_cross_entropy_with_logits(logit_ref, target).backward()
+
+    def fl(sdx, x_):
+        lg = om.discriminator_forward(sdx, x_, True, {})
+        return F.binary_cross_entropy_with_logits(lg, target.to(lg.dtype)), lg
+    _, g32, (dx32,), (logit_ref,) = oracle_grads(fl, sd, torch.float32, ((x, True),))
+    _, g64, (dx64,), _ = oracle_grads(fl, sd, torch.float64, ((x, True),))
     D.cuda().train()
     xg = x.cuda().requires_grad_(True)
     logit = D(xg)
     BCEWithLogitsLoss()(logit, target.cuda()).backward()
-    assert torch.allclose(logit.detach().cpu(), logit_ref.detach(), rtol=1e-3, atol=1e-4)
-    assert rel_err(xg.grad.cpu(), xr.grad) < 5e-3
+    assert torch.allclose(logit.detach().cpu(), logit_ref, rtol=1e-3, atol=1e-4)
+    assert_fp64_truth("dx", xg.grad.cpu(), dx32, dx64)
     for n, p in D.named_parameters():
-        assert rel_err(p.grad.cpu(), sd[n].grad) < 5e-3, n
+        assert_fp64_truth(n, p.grad.cpu(), g32[n], g64[n])
 
 
 @pytest.mark.parametrize("interval", [1, 2])
@@ -287,42 +316,12 @@ def test_train_engine_capture_failure_drops_every_graph(fail):
     """A hipGraph bakes in the tensors alive at capture time (D's graph reads the generator graph's static `sr`), so a mixed
     eager / graph engine would replay on stale buffers.  Force the capture of ONE half to fail (an illegal synchronize while
     capturing): the whole engine must fall back to eager - graph_active False, no graph kept - and the run must stay
-    bit-identical to an all-eager run."""
-    from srganst.engine import TrainEngine
-    from srganst.loss import MSELoss, StructureTensorLoss
-    from srganst.model import Discriminator, Generator
-
-    def run(use_graph, sabotage):
-        cfg = make_cfg(16, 2, 8)
-        torch.manual_seed(1)
-        D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
-        cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
-        cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
-        cfg.SOLVER.D_UPDATE_INTERVAL = 1
-        eng = TrainEngine(cfg, G, D, use_graph=use_graph, adam_capturable=True)
-        if sabotage:
-            step = eng._g_fb if sabotage == "g" else eng._d_fb
-            inner = step.fn
-
-            def fn():
-                if torch.cuda.is_current_stream_capturing():
-                    torch.cuda.synchronize()           # not allowed under capture: the capture fails
-                return inner()
-            step.fn = fn
-        gen = torch.Generator().manual_seed(2)
-        for _ in range(6):
-            eng.step(torch.rand(4, 3, 96, 96, generator=gen).cuda(), torch.rand(4, 3, 24, 24, generator=gen).cuda())
-        torch.cuda.synchronize()
-        return eng, G.state_dict(), D.state_dict(), {k: v.item() for k, v in eng.loss_values.items()}
-
-    e1, g1, d1, l1 = run(False, None)
-    e2, g2, d2, l2 = run(True, fail)
-    assert not e1.graph_active and not e2.graph_active
-    assert all(s.graph is None and not s.enabled for s in e2._steps())
-    for k in g1:
-        assert torch.equal(g1[k], g2[k]), k
-    for k in d1:
-        assert torch.equal(d1[k], d2[k]), k
-    assert l1 == l2
-    e3 = run(True, None)[0]
-    assert e3.graph_active
+    bit-identical to an all-eager run.  Runs in a child process (tests/capture_failure_child.py): a failed capture leaves
+    torch's capture bookkeeping of that process in an undefined state, which must not leak into the other tests."""
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capture_failure_child.py")
+    r = subprocess.run([sys.executable, child, fail], capture_output=True, text=True, timeout=600)
+    assert "FALLBACK-PARITY-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    assert "RECAPTURE-OK" in r.stdout and r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_fp64_truth, oracle_grads, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -46,8 +46,16 @@ def test_generator_small_two_adam_steps(golden):
             assert rel_err(sr.detach().cpu(), g["sr0"]) < 1e-4
             assert abs(l_pix.item() - g["loss_pixel0"].item()) < 1e-4 * abs(g["loss_pixel0"].item())
             assert abs(l_st.item() - g["loss_st0"].item()) < 1e-3 * abs(g["loss_st0"].item())
+            # fp64-truth criterion; fp32 side of the bound = the reference's own stored gradient
+            from oracle import model as om
+            from oracle import st as ost
+
+            def fl(sdx, lr_, gt_):
+                sr_ = om.generator_forward(sdx, lr_, True, {})
+                return torch.nn.functional.mse_loss(sr_, gt_) + ost.st_loss(sr_, gt_) / 3
+            _, g64, _, _ = oracle_grads(fl, sd0, torch.float64, ((T(g["lr"]), False), (T(g["gt"]), False)))
             for n, p in G.named_parameters():
-                assert rel_err(p.grad.cpu(), g["grad0/" + n]) < 3e-3, n
+                assert_fp64_truth(n, p.grad.cpu(), T(g["grad0/" + n]), g64[n])
         opt.step()
         sd = G.state_dict()
         for k in sd:
@@ -68,6 +76,7 @@ def test_generator_full_seed0(golden):
     sd = G.state_dict()
     for k in [f[2:] for f in g.files if f.startswith("w/")]:
         assert torch.equal(sd[k], T(g["w/" + k])), k                    # same RNG order as the reference
+    sd0 = {k: v.clone() for k, v in sd.items()}
     G.cuda().train()
     sr = G(T(g["lr"]).cuda())
     assert sr.shape == (2, 3, 96, 96) and float(sr.min()) >= 0 and float(sr.max()) <= 1
@@ -75,15 +84,24 @@ def test_generator_full_seed0(golden):
     loss = MSELoss()(sr, T(g["gt"]).cuda())
     assert abs(loss.item() - g["loss"].item()) < 1e-3 * g["loss"].item()
     loss.backward()
-    norms = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
+    # gradients: fp64-truth criterion (conftest.assert_fp64_truth).  The truth is the oracle (pinned to the reference by
+    # tests/test_oracle_golden.py) run in fp64 on the same weights / inputs; the fp32 side of the bound is the REFERENCE's own
+    # fp32 gradient where the fixture stores it (g/...), the oracle's fp32 run elsewhere.
+    from oracle import model as om
+
+    def fl(sdx, lr, gt):
+        return torch.nn.functional.mse_loss(om.generator_forward(sdx, lr, True, {}), gt)
+    ins = ((T(g["lr"]), False), (T(g["gt"]), False))
+    _, g32, _, _ = oracle_grads(fl, sd0, torch.float32, ins)
+    _, g64, _, _ = oracle_grads(fl, sd0, torch.float64, ins)
     named = dict(G.named_parameters())
+    stored = {f[2:] for f in g.files if f.startswith("g/")}
+    report = []
     for k, v in named.items():
-        # PReLU slopes are ONE scalar = a signed sum over every activation of the layer (590k..9.4M terms that largely
-        # cancel): their fp32 value moves by ~1 % with the summation order alone, in the reference as well.
-        tol = 5e-2 if v.numel() == 1 else 5e-3
-        assert abs(v.grad.norm().item() - norms[k]) <= tol * norms[k] + 1e-9, k
-    for k in [f[2:] for f in g.files if f.startswith("g/")]:
-        assert rel_err(named[k].grad.cpu(), g["g/" + k]) < (5e-2 if named[k].numel() == 1 else 5e-3), k
+        ref32 = T(g["g/" + k]) if k in stored else g32[k]
+        assert_fp64_truth(k, v.grad.cpu(), ref32, g64[k], report)
+    worst = max(report, key=lambda r: r[1])
+    print(f"worst param-grad error vs fp64: {worst[0]} {worst[1]:.2e} (oracle fp32: {worst[2]:.2e})")
     sd = G.state_dict()
     assert torch.allclose(sd["trunk.0.rcb.1.running_mean"].cpu(), T(g["bn/trunk.0.rcb.1.running_mean"]), rtol=1e-3, atol=1e-6)
     assert torch.allclose(sd["trunk.0.rcb.1.running_var"].cpu(), T(g["bn/trunk.0.rcb.1.running_var"]), rtol=1e-3, atol=1e-6)
@@ -100,16 +118,19 @@ def test_generator_vs_oracle_fresh_input():
     lr = torch.rand(16, 3, 24, 24, generator=gen)
     gt = torch.rand(16, 3, 96, 96, generator=gen)
     sd = {k: v.clone() for k, v in G.state_dict().items()}
-    for k in om.param_keys(sd):
-        sd[k].requires_grad_(True)
-    sr_ref = om.generator_forward(sd, lr, True, {})
-    torch.nn.functional.mse_loss(sr_ref, gt).backward()
+
+    def fl(sdx, lr_, gt_):
+        sr_ = om.generator_forward(sdx, lr_, True, {})
+        return torch.nn.functional.mse_loss(sr_, gt_), sr_
+    ins = ((lr, False), (gt, False))
+    _, g32, _, (sr_ref,) = oracle_grads(fl, sd, torch.float32, ins)
+    _, g64, _, _ = oracle_grads(fl, sd, torch.float64, ins)
     G.cuda().train()
     sr = G(lr.cuda())
     MSELoss()(sr, gt.cuda()).backward()
-    assert rel_err(sr.detach().cpu(), sr_ref.detach()) < 1e-3
+    assert rel_err(sr.detach().cpu(), sr_ref) < 1e-3
     for n, p in G.named_parameters():
-        assert rel_err(p.grad.cpu(), sd[n].grad) < 5e-3, n
+        assert_fp64_truth(n, p.grad.cpu(), g32[n], g64[n])
 
 
 def test_generator_eval_and_no_cpu_fallback():
@@ -181,11 +202,13 @@ def test_generator_vs_oracle_hr192():
     lr = torch.rand(2, 3, 48, 48, generator=gen)
     gt = torch.rand(2, 3, 192, 192, generator=gen)
     sd = {k: v.clone() for k, v in G.state_dict().items()}
-    for k in om.param_keys(sd):
-        sd[k].requires_grad_(True)
-    sr_ref = om.generator_forward(sd, lr, True, {})
-    l_ref = torch.nn.functional.mse_loss(sr_ref, gt) + ost.st_loss(sr_ref, gt) / 3
-    l_ref.backward()
+
+    def fl(sdx, lr_, gt_):
+        sr_ = om.generator_forward(sdx, lr_, True, {})
+        return torch.nn.functional.mse_loss(sr_, gt_) + ost.st_loss(sr_, gt_) / 3, sr_
+    ins = ((lr, False), (gt, False))
+    l_ref, g32, _, (sr_ref,) = oracle_grads(fl, sd, torch.float32, ins)
+    _, g64, _, _ = oracle_grads(fl, sd, torch.float64, ins)
     n0 = _abi.lib().sst_debug_band_launches()
     G.cuda().train()
     sr = G(lr.cuda())
@@ -196,4 +219,4 @@ def test_generator_vs_oracle_hr192():
     assert rel_err(sr.detach().cpu(), sr_ref.detach()) < 1e-3
     assert abs(loss.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
     for n, p in G.named_parameters():
-        assert rel_err(p.grad.cpu(), sd[n].grad) < 5e-3, n
+        assert_fp64_truth(n, p.grad.cpu(), g32[n], g64[n])
