@@ -73,6 +73,22 @@ int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const 
                  float in_slope_const, int in_act, const float* residual, float* stats,
                  float* stats_cnt, int out_mode, int B, int H, int W, int Cin, int Cout, int ksize,
                  int stride, void* stream);
+/* ---- persistent, software-pipelined form of the 3x3 conv (csrc/conv_pipe.hip) for the discriminator's layers
+ * (model.py:30-59) and their stride-1 data-gradients: Cin % 64 == 0, Cout % 32 == 0, NHWC store, stride 1 / 2 (even H, W),
+ * at least 256 tiles of 32 px x 32 ch.  The batch is tiled as one tall image (no MFMA lanes on padding pixels of the
+ * 12 x 12 / 6 x 6 layers), the next input patch and the weight fragments are in flight while the MFMAs of the current
+ * stage run, layers with few tiles split K over workgroups (partial slabs in `ws`, summed in fixed order).
+ * sst_conv_pipe_supported: the tile width (8 / 4 / 2) when the shape is taken, else 0 (the 64 -> 64 trunk shape of the band kernel is never taken).  stats / stats_cnt / epi_partial have sst_conv_pipe_stat_tiles rows
+ * (a different tiling than sst_conv_stat_tiles); ws = sst_conv_pipe_ws_floats floats (0: not needed).
+ * Arguments as sst_conv_fwd (forward statistics) / sst_conv_dgrad_bwdstats (epi_*: backward partials). */
+int sst_conv_pipe_supported(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int sst_conv_pipe_stat_tiles(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int64_t sst_conv_pipe_ws_floats(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const float* bias, const float* in_scale,
+                      const float* in_shift, const float* in_slope, float in_slope_const, int in_act, float* stats,
+                      float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
+                      const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
+                      int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
 /* stride-1 data-gradient (mode 1 weights) whose epilogue also emits the BatchNorm/activation BACKWARD partial sums of
  * its result g against the saved conv output epi_y: epi_partial [sst_conv_stat_tiles][3][Cout] = per-tile sums of
  * (gz, gz*epi_y, g*min(z,0)) - the layout sst_bwd_finalize consumes (replaces a separate sst_bwd_reduce pass). */

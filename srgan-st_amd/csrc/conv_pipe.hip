@@ -1,0 +1,510 @@
+// 3x3 convolution (pad 1, stride 1 or 2), NHWC, fp32 MFMA implicit GEMM - PERSISTENT, SOFTWARE-PIPELINED form for the
+// discriminator's layers (reference model.py:30-59: 64..512 channels at 96..6 px) and their stride-1 data-gradients.
+//
+// Why a second general kernel (conv_fwd.hip stays for every shape this one does not take): on these shapes conv_fwd_kernel
+// runs stage -> barrier -> K loop -> epilogue once per workgroup with nothing overlapped inside a workgroup, one workgroup
+// per 32 px x 32 ch tile (4,608 dispatches for the 48-px layer) and an 8x4 pixel tile that wastes 25-44 % of every MFMA on
+// the 12x12 / 6x6 layers; measured (tools/ablate_d.py) its K loop alone reaches 50-68 % of the fp32 MFMA peak and staging +
+// epilogue add their full time on top.  Here:
+//   * the batch is ONE TALL IMAGE of B*Ho rows: a tile is TW x (32/TW) pixels of it (TW = 8 / 4 / 2 chosen so that TW
+//     divides Wo), tiles may straddle images.  The LDS patch holds rows of a virtual tall input in which consecutive images
+//     are separated by ONE shared zero row (bottom pad of image b = top pad of image b+1); every lane adds its own
+//     crossed-boundary count to its patch row, so no MFMA lane is spent on padding pixels;
+//   * a fixed grid of workgroups (GPC per CU) walks its share of the work units (unit = tile x K-split part); while the MFMAs
+//     of stage s run, the global loads of stage s+1's input patch are in flight in registers (written to LDS behind the
+//     K loop) and the weight fragments come through a 9-deep register ring that is refilled one half stage ahead - the
+//     K loop is fully unrolled (18 chunks per wave and 64-channel block: wave w owns k-steps {2w, 2w+1} of every tap), all
+//     LDS / weight offsets are immediates;
+//   * layers with few tiles split K over workgroups (fp32 partial slabs in a caller-provided workspace, summed in fixed order
+//     by pipe_reduce_kernel, which then runs the same epilogue): every launch offers >= 4 equal units per CU.
+// GEMM view, fragment layouts, packed weights (conv_common.h: packed_index) and the epilogue's arithmetic (bias, per-tile
+// BatchNorm statistics (sum, centred M2), BatchNorm/activation backward partials) are those of conv_fwd.hip.
+#include "conv_common.h"
+#include <cstdlib>
+#include "conv_epilogue.h"
+
+int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride);   // conv_band.hip: trunk shapes stay there
+
+namespace {
+
+constexpr int PIPE_RING = 9;   // weight-fragment ring (chunks): refilled half a stage ahead
+
+struct PipeArgs {
+  const float* x;           // [B,H,W,Cin]
+  const float* wp;          // packed weights (forward or stride-1 data-gradient layout)
+  float* y;                 // [B,Ho,Wo,Cout]
+  const float* bias;
+  const float* in_scale; const float* in_shift; const float* in_slope; float in_slope_const; int in_act;
+  float* stats; float* stats_cnt;                      // [n_mt][2][Cout], [n_mt] or null
+  const float* epi_y; const float* epi_scale; const float* epi_shift; const float* epi_slope;
+  float epi_slope_const; int epi_act; float* epi_partial;   // [n_mt][3][Cout] or null
+  float* ws;                // split-K slabs [ksplit][total_tiles][32 px][32 ch] (ksplit > 1)
+  int B, H, W, Cin, Cout, Ho, Wo;
+  int R;                    // B*Ho: rows of the tall output image
+  int tiles_x, n_mt, nfc, total_tiles, ncb, ksplit, cb_per, units;
+  int dbg;
+};
+
+template <int S, int TW>
+struct PipeGeom {
+  static constexpr int TH = 32 / TW;
+  static constexpr int NB = TW == 2 ? 3 : 1;                 // image boundaries a tile may cross (host checks Ho against it)
+  static constexpr int PW = (TW - 1) * S + 3;
+  static constexpr int PR = (TH - 1) * S + 3 + NB;
+  static constexpr int NP = PW * PR;
+  static constexpr int NU = (NP + 15) / 16;                  // patch pixels per thread (16 threads x 16 B per pixel)
+  static constexpr int LDS_FLOATS = NP * LDSC > 4 * 32 * 33 ? NP * LDSC : 4 * 32 * 33;
+};
+
+// one stage = one 64-channel block of one tile's input patch (+ the matching weight block)
+struct Stage {
+  int b0, rem0, ix0, c0;       // image / virtual row inside it of patch row 0, first patch column, first channel
+  const float* w;              // this wave's weight pointer for the block (wave-uniform: + wave*512 floats; lanes add lane*16 B)
+};
+
+// Vector-memory loads of the main loop are issued by hand and waited for by hand with COUNTED s_waitcnt vmcnt(N): hipcc's own
+// waitcnt insertion falls back to vmcnt(0) around this loop's back edge (every weight refill became a full stall).  Loads
+// return in order, so "at most N outstanding" proves that everything older than the N youngest loads has landed; stores the
+// compiler issues in an epilogue only ever make such a wait longer, never too short.  The "+v" operand ties the consumer of a
+// register to its wait.  __builtin_amdgcn_sched_barrier(0) after every chunk keeps the compiler from moving code across.
+// (s_nop 4: the compiler may hand the base pointer over in SGPRs it has just restored with v_readlane - a VALU write of an SGPR
+// needs 5 wait states before a vector-memory instruction reads it, and the hazard recognizer does not look inside inline asm.)
+#define PIPE_GLOAD(dst, voff, sbase) \
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase))
+#define PIPE_WAIT(reg, n) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n))
+
+// Epilogue of one 32 px x 32 ch tile for thread (pixel p = tid >> 3, channels cq..cq+3 of block nf), v = conv result.
+// Contains workgroup barriers: call from all 256 threads.
+template <int TW>
+__device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float (*sstat)[3][32], float v[4], int r0, int ox0, int nf, int mt,
+                                              int tid, int wave, int lane) {
+  constexpr int TH = 32 / TW;
+  const int p = tid >> 3, cq = (tid & 7) * 4;
+  const int r = r0 + p / TW, ox = ox0 + p % TW;
+  const int n0 = nf * 32 + cq;
+  const bool pix_ok = r < a.R && ox < a.Wo;
+  if (a.bias) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += bv[j];
+  }
+  const size_t obase = ((size_t)r * a.Wo + ox) * a.Cout + n0;
+  if (pix_ok) *reinterpret_cast<f32x4*>(a.y + obase) = f32x4{v[0], v[1], v[2], v[3]};
+  if (a.stats) {
+    const int nvalid = min(TH, a.R - r0) * min(TW, a.Wo - ox0);
+    float s1[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = pix_ok ? v[j] : 0.f;
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      s1[j] = s;
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sstat[wave][0][lane * 4 + j] = s1[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float tot = sstat[0][0][cq + j] + sstat[1][0][cq + j] + sstat[2][0][cq + j] + sstat[3][0][cq + j];
+      const float mean = tot / (float)nvalid;
+      float d = pix_ok ? (v[j] - mean) : 0.f;
+      d = d * d;
+      d += __shfl_xor(d, 8, 64);
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      m2[j] = d;
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sstat[wave][1][lane * 4 + j] = m2[j];
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const float tot = sstat[0][0][tid] + sstat[1][0][tid] + sstat[2][0][tid] + sstat[3][0][tid];
+      const float m2t = sstat[0][1][tid] + sstat[1][1][tid] + sstat[2][1][tid] + sstat[3][1][tid];
+      float* st = a.stats + (size_t)mt * 2 * a.Cout;
+      st[nf * 32 + tid] = tot;
+      st[a.Cout + nf * 32 + tid] = m2t;
+      if (tid == 0 && nf == 0) a.stats_cnt[mt] = (float)nvalid;
+    }
+  }
+  if (a.epi_partial) {
+    const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
+    float q[3][4];
+    f32x4 yv = {0.f, 0.f, 0.f, 0.f}, es = {1.f, 1.f, 1.f, 1.f}, eh = {0.f, 0.f, 0.f, 0.f};
+    if (pix_ok) yv = *reinterpret_cast<const f32x4*>(a.epi_y + obase);
+    if (a.epi_scale) {
+      es = *reinterpret_cast<const f32x4*>(a.epi_scale + n0);
+      eh = *reinterpret_cast<const f32x4*>(a.epi_shift + n0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = pix_ok ? v[j] : 0.f;
+      const float z = a.epi_scale ? fmaf(yv[j], es[j], eh[j]) : yv[j];
+      float gz = g, q2 = 0.f;
+      if (a.epi_act) {
+        q2 = g * fminf(z, 0.f);
+        gz = z > 0.f ? g : g * eslope;
+      }
+      q[0][j] = gz;
+      q[1][j] = gz * yv[j];
+      q[2][j] = q2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = q[k][j];
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        q[k][j] = t;
+      }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sstat[wave][k][lane * 4 + j] = q[k][j];
+    }
+    __syncthreads();
+    if (tid < 96) {
+      const int k = tid >> 5, c = tid & 31;
+      a.epi_partial[((size_t)mt * 3 + k) * a.Cout + nf * 32 + c] = sstat[0][k][c] + sstat[1][k][c] + sstat[2][k][c] + sstat[3][k][c];
+    }
+  }
+}
+
+template <int S, int TW>
+__global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(PipeArgs a) {
+  using G = PipeGeom<S, TW>;
+  constexpr int PW = G::PW, NP = G::NP, NU = G::NU, NB = G::NB;
+  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+  __shared__ float sstat[4][3][32];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nwg = gridDim.x;
+  const int HV = a.H + 1;                                 // rows of one image in the virtual tall input (its top zero row + H)
+  const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
+  const int c4 = (tid & 15) * 4;                          // this thread's channel quad inside a 64-channel block (staging)
+  const int p0 = tid >> 4;                                // its first patch pixel
+
+  // ---- unit / stage sequencing (all wave-uniform)
+  int q = blockIdx.x;                                     // current unit
+  if (q >= a.units) return;
+  int mt, nf, r0, ox0, oy0, cb, cb_end;                   // of the CURRENT unit
+  Stage cur, nxt;
+  auto decode = [&](int qq, int& mt_, int& nf_, int& ksi_, int& r0_, int& ox0_, int& b0_, int& oy0_) {
+    mt_ = qq % a.n_mt;
+    const int rest = qq / a.n_mt;
+    nf_ = rest % a.nfc;
+    ksi_ = rest / a.nfc;
+    const int ty = mt_ / a.tiles_x, tx = mt_ - ty * a.tiles_x;
+    r0_ = ty * G::TH;
+    ox0_ = tx * TW;
+    b0_ = r0_ / a.Ho;
+    oy0_ = r0_ - b0_ * a.Ho;
+  };
+  auto make_stage = [&](int b0_, int oy0_, int ox0_, int nf_, int cb_) {
+    Stage s;
+    s.b0 = b0_;
+    s.rem0 = oy0_ * S;
+    s.ix0 = ox0_ * S - 1;
+    s.c0 = cb_ * CB;
+    s.w = a.wp + ((size_t)(nf_ * a.ncb + cb_) * 9 * 8) * 256 + wave * 512;
+    return s;
+  };
+  int ksi, b0;
+  decode(q, mt, nf, ksi, r0, ox0, b0, oy0);
+  cb = ksi * a.cb_per;
+  cb_end = cb + a.cb_per;
+  cur = make_stage(b0, oy0, ox0, nf, cb);
+
+  // ---- staging: loads of one stage's patch into registers / transform + LDS write.  NS = loads per stage_load call.
+  constexpr int NS = NU + 2;
+  f32x4 sv[NU];
+  unsigned okmask = 0;
+  f32x4 ssc, ssh;
+  const float* sc_base = a.in_scale ? a.in_scale : a.x;          // no affine: two dummy (never used) loads keep the load count fixed
+  const float* sh_base = a.in_scale ? a.in_shift : a.x;
+  auto stage_load = [&](const Stage& s) {
+    okmask = 0;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int p = p0 + 16 * u;
+      const int pr = p / PW, pc = p - pr * PW;
+      int rr = s.rem0 + pr, b = s.b0;
+#pragma unroll
+      for (int k = 0; k <= NB; ++k) {
+        const bool wrap = rr >= HV;
+        rr -= wrap ? HV : 0;
+        b += wrap ? 1 : 0;
+      }
+      const int iy = rr - 1, ix = s.ix0 + pc;
+      const bool ok = p < NP && rr >= 1 && b < a.B && (unsigned)ix < (unsigned)a.W;
+      const int off = ((b * a.H + iy) * a.W + ix) * a.Cin + s.c0 + c4;          // < 2^29 floats (host check)
+      const unsigned boff = (ok ? (unsigned)off : (unsigned)c4) * 4u;
+      PIPE_GLOAD(sv[u], boff, a.x);
+      okmask |= ok ? (1u << u) : 0u;
+    }
+    const unsigned coff = (unsigned)(a.in_scale ? s.c0 + c4 : c4) * 4u;
+    PIPE_GLOAD(ssc, coff, sc_base);
+    PIPE_GLOAD(ssh, coff, sh_base);
+  };
+  auto stage_store = [&]() {
+    if (a.dbg & 1) return;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int p = p0 + 16 * u;
+      if (p >= NP) continue;
+      f32x4 t = sv[u];
+      if (a.in_scale) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = fmaf(t[j], ssc[j], ssh[j]);
+      }
+      if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = t[j] > 0.f ? t[j] : t[j] * slope;
+      }
+      if (!((okmask >> u) & 1u)) t = f32x4{0.f, 0.f, 0.f, 0.f};            // zero padding stays exactly zero
+      *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = t;
+    }
+  };
+
+  // ---- this lane's A-fragment base in the patch: pixel li of the tile (+ 4*lh channels, + this wave's two k-steps)
+  auto lane_base = [&](int oy0_) {
+    const int tr = li / TW, tc = li - tr * TW;
+    int cross = 0;
+#pragma unroll
+    for (int k = 1; k <= NB; ++k) cross += (oy0_ + tr >= k * a.Ho) ? 1 : 0;
+    return ((S * tr + cross) * PW + tc * S) * LDSC + 4 * lh + wave * 16;
+  };
+  int a_base = lane_base(oy0);
+
+  // ---- weight ring: chunk i of a stage = tap i/2, k-step 2*wave + (i&1)
+  f32x4 ring[PIPE_RING];
+  const unsigned wlane = lane * 16u;
+#define PIPE_WCHUNK(dst, w, i) PIPE_GLOAD(dst, wlane, (w) + (((i) >> 1) * 8 + ((i) & 1)) * 256)
+
+  // prologue: first stage
+#pragma unroll
+  for (int i = 0; i < PIPE_RING; ++i) PIPE_WCHUNK(ring[i], cur.w, i);
+  stage_load(cur);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  stage_store();
+  __syncthreads();
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (;;) {
+    // ---- what comes after the current stage (wave-uniform)
+    const bool unit_end = cb + 1 == cb_end;
+    int n_q = q, n_mt = mt, n_nf = nf, n_r0 = r0, n_ox0 = ox0, n_oy0 = oy0, n_cb = cb + 1, n_cb_end = cb_end;
+    bool more = true;
+    if (unit_end) {
+      n_q = q + nwg;
+      more = n_q < a.units;
+      if (more) {
+        int n_ksi, n_b0;
+        decode(n_q, n_mt, n_nf, n_ksi, n_r0, n_ox0, n_b0, n_oy0);
+        n_cb = n_ksi * a.cb_per;
+        n_cb_end = n_cb + a.cb_per;
+        nxt = make_stage(n_b0, n_oy0, n_ox0, n_nf, n_cb);
+      } else {
+        nxt = cur;                        // harmless re-loads of the last stage (never stored)
+      }
+    } else {
+      nxt = cur;
+      nxt.c0 += CB;
+      nxt.w += (size_t)9 * 8 * 256;
+    }
+
+    // ---- K loop of the current stage: 18 chunks x 4 MFMAs; the next stage's patch loads go out behind the first chunk.
+    // Outstanding loads when chunk i waits, oldest first (x' = issued during this stage):
+    //   i = 0      : slots 0..8                                   -> slot 0 has landed at vmcnt(8)
+    //   i = 1..8   : slots i..8, 0'..(i-1)' with the NS patch loads after 0'   -> vmcnt(8 + NS)
+    //   i = 9      : 0', patch loads, 1'..8'                      -> vmcnt(8 + NS)
+    //   i = 10..17 : patch loads, i'.., next stage's slots        -> vmcnt(8): the patch has landed as well
+    {
+      const float* ab = lds + a_base;
+      f32x4 av = *reinterpret_cast<const f32x4*>(ab);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        f32x4 an = av;
+        if (i + 1 < 18) {
+          const int t = (i + 1) >> 1;
+          an = *reinterpret_cast<const f32x4*>(ab + ((t / 3) * PW + (t % 3)) * LDSC + ((i + 1) & 1) * 8);
+        }
+        if (i == 0 || i >= 10) PIPE_WAIT(ring[i % PIPE_RING], 8); else PIPE_WAIT(ring[i % PIPE_RING], 8 + NS);
+        const f32x4 bv = ring[i % PIPE_RING];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+        if (i + PIPE_RING < 18) PIPE_WCHUNK(ring[i % PIPE_RING], cur.w, i + PIPE_RING);
+        else PIPE_WCHUNK(ring[i % PIPE_RING], nxt.w, i + PIPE_RING - 18);
+        if (i == 0) stage_load(nxt);
+        av = an;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                       // every wave is done reading the patch
+
+    if (unit_end && (a.dbg & 2)) {
+      if (acc[0] == 12345.f) a.y[0] = acc[0];
+      if (!more) return;
+      a_base = lane_base(n_oy0);
+    } else if (unit_end) {
+      // ---- the 4 waves' K-partials -> LDS -> one value quad per thread
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        lds[(wave * 32 + row) * 33 + li] = acc[r];
+        acc[r] = 0.f;
+      }
+      __syncthreads();
+      const int p = tid >> 3, cq = (tid & 7) * 4;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = lds[(0 * 32 + p) * 33 + cq + j];
+        s += lds[(1 * 32 + p) * 33 + cq + j];
+        s += lds[(2 * 32 + p) * 33 + cq + j];
+        s += lds[(3 * 32 + p) * 33 + cq + j];
+        v[j] = s;
+      }
+      if (a.ksplit > 1) {
+        const int tile = nf * a.n_mt + mt;
+        const int part = cb / a.cb_per;
+        *reinterpret_cast<f32x4*>(a.ws + ((size_t)part * a.total_tiles + tile) * 1024 + p * 32 + cq) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        pipe_epilogue<TW>(a, sstat, v, r0, ox0, nf, mt, tid, wave, lane);
+      }
+      __syncthreads();                     // scratch (overlays the patch) is free again
+      if (!more) return;
+      a_base = lane_base(n_oy0);
+    }
+    stage_store();                         // next stage's patch: registers -> LDS
+    __syncthreads();
+    q = n_q; mt = n_mt; nf = n_nf; r0 = n_r0; ox0 = n_ox0; oy0 = n_oy0; cb = n_cb; cb_end = n_cb_end;
+    cur = nxt;
+  }
+}
+
+// Split-K: sum the partial slabs of one tile in fixed order, then the ordinary epilogue.
+template <int TW>
+__global__ __launch_bounds__(CONV_NT) void pipe_reduce_kernel(PipeArgs a) {
+  __shared__ float sstat[4][3][32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = blockIdx.x;
+  const int nf = tile / a.n_mt, mt = tile - nf * a.n_mt;
+  const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
+  const int p = tid >> 3, cq = (tid & 7) * 4;
+  f32x4 s = *reinterpret_cast<const f32x4*>(a.ws + (size_t)tile * 1024 + p * 32 + cq);
+  for (int k = 1; k < a.ksplit; ++k) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(a.ws + ((size_t)k * a.total_tiles + tile) * 1024 + p * 32 + cq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += t[j];
+  }
+  float v[4] = {s[0], s[1], s[2], s[3]};
+  pipe_epilogue<TW>(a, sstat, v, ty * (32 / TW), tx * TW, nf, mt, tid, wave, lane);
+}
+
+struct PipePlan {
+  int tw;          // 0 = shape not taken
+  int ksplit, n_mt, tiles_x, nfc, ncb;
+};
+
+PipePlan pipe_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  PipePlan pl{};
+  if (ksize != 3 || (stride != 1 && stride != 2) || (Cin % 64) || (Cout % 32) || B <= 0) return pl;
+  if (stride == 2 && ((H | W) & 1)) return pl;
+  if (Cout <= 64 && sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride)) return pl;   // the generator's trunk shape stays on the band kernel
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  int tw = 0;
+  if (Wo % 8 == 0 && Ho >= 3) tw = 8;
+  else if (Wo % 4 == 0 && Ho >= 7) tw = 4;
+  else if (Wo % 2 == 0 && Ho >= 5) tw = 2;
+  if (!tw) return pl;
+  const int th = 32 / tw;
+  pl.tiles_x = Wo / tw;
+  pl.n_mt = pl.tiles_x * ((B * Ho + th - 1) / th);
+  pl.nfc = Cout / 32;
+  pl.ncb = Cin / 64;
+  const long tiles = (long)pl.n_mt * pl.nfc;
+  int maxks = 1;
+  while (maxks < 4 && pl.ncb % (maxks * 2) == 0) maxks *= 2;
+  if (tiles * maxks < 256) return pl;     // too little work to fill the chip this way: the general kernel keeps it
+  int ks = 1;
+  while (tiles * ks < 1024 && ks < maxks) ks *= 2;
+  pl.ksplit = ks;
+  pl.tw = tw;
+  return pl;
+}
+
+constexpr int PIPE_CUS = 256;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+SST_API int sst_conv_pipe_supported(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  return pipe_plan(B, H, W, Cin, Cout, ksize, stride).tw;      // tile width (8 / 4 / 2) when taken, else 0
+}
+SST_API int sst_conv_pipe_stat_tiles(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  return pipe_plan(B, H, W, Cin, Cout, ksize, stride).n_mt;
+}
+SST_API int64_t sst_conv_pipe_ws_floats(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  const PipePlan pl = pipe_plan(B, H, W, Cin, Cout, ksize, stride);
+  return (pl.tw && pl.ksplit > 1) ? (int64_t)pl.ksplit * pl.n_mt * pl.nfc * 1024 : 0;
+}
+
+SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const float* bias, const float* in_scale,
+                              const float* in_shift, const float* in_slope, float in_slope_const, int in_act, float* stats,
+                              float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
+                              const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
+                              int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+  SST_REQUIRE(x && wp && y, "sst_conv_pipe_fwd: null pointer");
+  const PipePlan pl = pipe_plan(B, H, W, Cin, Cout, ksize, stride);
+  SST_REQUIRE(pl.tw, "sst_conv_pipe_fwd: shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d stride=%d is not taken by the pipelined kernel", B,
+              H, W, Cin, Cout, ksize, stride);
+  SST_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sst_conv_pipe_fwd: in_scale/in_shift must come together");
+  SST_REQUIRE(!stats || stats_cnt, "sst_conv_pipe_fwd: stats needs stats_cnt");
+  SST_REQUIRE(!epi_partial || (epi_y && !stats && ((epi_scale == nullptr) == (epi_shift == nullptr))),
+              "sst_conv_pipe_fwd: backward partials need epi_y and exclude forward stats");
+  SST_REQUIRE(pl.ksplit == 1 || ws, "sst_conv_pipe_fwd: this shape splits K over workgroups and needs the workspace");
+  SST_REQUIRE((int64_t)B * H * W * Cin < (1ll << 29), "sst_conv_pipe_fwd: input too large for 32-bit byte offsets");
+  PipeArgs a;
+  a.x = x; a.wp = wp; a.y = y; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
+  a.in_slope_const = in_slope_const; a.in_act = in_act; a.stats = stats; a.stats_cnt = stats_cnt;
+  a.epi_y = epi_y; a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_slope = epi_slope; a.epi_slope_const = epi_slope_const;
+  a.epi_act = epi_act; a.epi_partial = epi_partial; a.ws = ws;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.R = B * a.Ho;
+  a.tiles_x = pl.tiles_x; a.n_mt = pl.n_mt; a.nfc = pl.nfc; a.total_tiles = pl.n_mt * pl.nfc; a.ncb = pl.ncb;
+  a.ksplit = pl.ksplit; a.cb_per = pl.ncb / pl.ksplit; a.units = a.total_tiles * pl.ksplit;
+  a.dbg = getenv("SST_PIPE_DBG") ? atoi(getenv("SST_PIPE_DBG")) : 0;     // ablation bits (tools/ablate_pipe.py): 1 no LDS staging writes, 2 no epilogue
+  const int wg_per_cu = stride == 1 ? 3 : 2;           // = the kernels' launch bounds (register-limited)
+  const int grid = a.units < wg_per_cu * PIPE_CUS ? a.units : wg_per_cu * PIPE_CUS;
+  hipStream_t st = sst_stream(stream);
+#define SST_PIPE_LAUNCH(S_, TW_)                                                                  \
+  do {                                                                                            \
+    conv_pipe_kernel<S_, TW_><<<grid, CONV_NT, 0, st>>>(a);                                       \
+    SST_LAUNCH_CHECK("conv_pipe_kernel");                                                         \
+    if (pl.ksplit > 1) {                                                                          \
+      pipe_reduce_kernel<TW_><<<a.total_tiles, CONV_NT, 0, st>>>(a);                              \
+      SST_LAUNCH_CHECK("pipe_reduce_kernel");                                                     \
+    }                                                                                             \
+  } while (0)
+  if (stride == 1) {
+    if (pl.tw == 8) SST_PIPE_LAUNCH(1, 8); else if (pl.tw == 4) SST_PIPE_LAUNCH(1, 4); else SST_PIPE_LAUNCH(1, 2);
+  } else {
+    if (pl.tw == 8) SST_PIPE_LAUNCH(2, 8); else if (pl.tw == 4) SST_PIPE_LAUNCH(2, 4); else SST_PIPE_LAUNCH(2, 2);
+  }
+#undef SST_PIPE_LAUNCH
+  return SST_OK;
+}

@@ -100,6 +100,10 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
         y = _f32(B, cout, ho, wo, like=x)
     else:
         y = _f32(B, ho // 2, wo // 2, cout * 4, like=x)
+    if out_mode == OUT_NHWC and residual is None and not want_pre and conv_pipe_tw(B, H, W, cin, cout, ksize, stride):
+        y, stats, cnt, _ = _conv_pipe(x, wp, y, cout, ksize, stride, bias, in_scale, in_shift, in_slope, in_slope_const, in_act,
+                                      want_stats)
+        return y, None, stats, cnt
     y_pre = torch.empty_like(y) if want_pre else None
     stats = cnt = None
     if want_stats:
@@ -116,6 +120,44 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
     _trace(name, flops, lambda: _abi.lib().sst_conv_fwd(*args, stream_ptr()),
            x, wp, y, y_pre, bias, in_scale, in_shift, in_slope, residual, stats, cnt)
     return y, y_pre, stats, cnt
+
+
+def conv_pipe_tw(B, H, W, cin, cout, ksize, stride):
+    """Tile width of the persistent pipelined conv kernel (csrc/conv_pipe.hip) when it takes this NHWC-store shape, else 0.
+    SST_CONV_PIPE=0 (dev switch) keeps every shape on the general kernel."""
+    if os.environ.get("SST_CONV_PIPE", "1") == "0":
+        return 0
+    return _abi.lib().sst_conv_pipe_supported(B, H, W, cin, cout, ksize, stride)
+
+
+def _conv_pipe(x, wp, y, cout, ksize, stride, bias=None, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,
+               in_act=ACT_NONE, want_stats=False, epi=None):
+    """sst_conv_pipe_fwd: forward statistics (want_stats) or backward partials (epi = dict(y, scale, shift, slope, slope_const,
+    act)); returns (y, stats, cnt, partial)."""
+    B, H, W, cin = x.shape
+    L = _abi.lib()
+    shp = (B, H, W, cin, cout, ksize, stride)
+    stats = cnt = partial = None
+    if want_stats:
+        mt = L.sst_conv_pipe_stat_tiles(*shp)
+        stats, cnt = _f32(mt, 2, cout, like=x), _f32(mt, like=x)
+    e = epi or {}
+    if epi is not None:
+        partial = _f32(L.sst_conv_pipe_stat_tiles(*shp), 3, cout, like=x)
+    nws = L.sst_conv_pipe_ws_floats(*shp)
+    ws = _f32(nws, like=x) if nws else None
+    args = (ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const), int(in_act),
+            ptr(stats), ptr(cnt), ptr(e.get("y")), ptr(e.get("scale")), ptr(e.get("shift")), ptr(e.get("slope")),
+            float(e.get("slope_const", 0.0)), int(e.get("act", 0)), ptr(partial), ptr(ws), *shp)
+    e0 = _prof_begin()
+    check(L.sst_conv_pipe_fwd(*args, stream_ptr()), "sst_conv_pipe_fwd")
+    ho, wo = conv_out_hw(H, W, ksize, stride)
+    flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
+    name = f"conv_pipe_kernel<{stride}, {L.sst_conv_pipe_supported(*shp)}>" if (PROFILE is not None or TRACE is not None) else ""
+    _prof_end(e0, name, flops)
+    _trace(name, flops, lambda: L.sst_conv_pipe_fwd(*args, stream_ptr()),
+           x, wp, y, bias, in_scale, in_shift, in_slope, stats, cnt, partial, ws, *[v for v in e.values() if torch.is_tensor(v)])
+    return y, stats, cnt, partial
 
 
 _ONES = {}
@@ -712,6 +754,10 @@ def conv_dgrad_bwdstats(dy, wd, cout, ksize, epi_y, residual=None, epi_scale=Non
     against epi_y ([mtiles,3,cout], the layout bwd_finalize consumes)."""
     B, H, W, cin = dy.shape
     g = _f32(B, H, W, cout, like=dy)
+    if residual is None and conv_pipe_tw(B, H, W, cin, cout, ksize, 1):
+        _, _, _, partial = _conv_pipe(dy, wd, g, cout, ksize, 1, epi=dict(y=epi_y, scale=epi_scale, shift=epi_shift, slope=epi_slope,
+                                                                         slope_const=epi_slope_const, act=epi_act))
+        return g, partial
     mt = _abi.lib().sst_conv_stat_tiles(B, H, W, cin, cout, ksize, 1)
     partial = _f32(mt, 3, cout, like=dy)
     args = (ptr(dy), ptr(wd), ptr(g), ptr(residual), ptr(epi_y), ptr(epi_scale), ptr(epi_shift), ptr(epi_slope),

@@ -258,6 +258,7 @@ def test_conv_big_tile_kernel(ops, case, monkeypatch):
     """The 64x64-tile kernel (forced with SST_CONV_BIG=1) against fp64 conv2d: plain / prologue+stats+residual / shuffle /
     data-gradient with backward partials."""
     monkeypatch.setenv("SST_CONV_BIG", "1")
+    monkeypatch.setenv("SST_CONV_PIPE", "0")        # keep the pipelined kernel (tests/test_conv_pipe_gpu.py) off these shapes
     from srganst import _abi
     n_before = _abi.lib().sst_debug_big_tile_launches()
     B, H, W, Cin, Cout, s = case
