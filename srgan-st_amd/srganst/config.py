@@ -99,6 +99,7 @@ class Config:
         self.DIST = dotdict()
         self.DIST.BACKEND = "nccl"          # RCCL on ROCm; "gloo" in the CPU tests
         self.DIST.BUCKET_D = True           # D grads in two buckets (features / classifier)
+        self.DIST.OVERLAP_COMM = True       # hide the gradient all-reduces behind compute (engine.TrainEngine._step_overlapped)
         self.KERNEL = dotdict()
         self.KERNEL.USE_GRAPH = True        # capture the train step into a hipGraph
         self.KERNEL.SYNC_LOSS_EVERY_STEP = False  # reference does .item() per criterion per step (train.py:141)

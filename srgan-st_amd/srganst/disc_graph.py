@@ -84,13 +84,13 @@ def forward(module, x, p, training, need_grad=False):
     return out, sv
 
 
-def backward(module, p, sv, dout, need_param_grads, need_dx):
-    grads = {}
+def _grad_views(module, p, need_param_grads):
+    """Per-parameter gradient views of ONE flat buffer + whether this pass accumulates into it.
+    Two backward passes per D step (D(gt) and D(sr), train.py:155-161): when the step engine opened an accumulation scope
+    (module._grad_accum), the second pass ADDS into the first pass's flat buffer with the kernels' accumulate flag and hands
+    autograd nothing - p.grad stays a view of ONE flat buffer (flat Adam, single RCCL message) and autograd's own
+    out-of-place sum of two 94 MB gradient sets disappears."""
     names = list(p.keys())
-    # Two backward passes per D step (D(gt) and D(sr), train.py:155-161): when the step engine opened an accumulation scope
-    # (module._grad_accum), the second pass ADDS into the first pass's flat buffer with the kernels' accumulate flag and hands
-    # autograd nothing - p.grad stays a view of ONE flat buffer (flat Adam, single RCCL message) and autograd's own
-    # out-of-place sum of two 94 MB gradient sets disappears.
     scope = module.__dict__.get("_grad_accum") if need_param_grads else None
     acc = scope is not None and scope.get("flat") is not None
     if acc:
@@ -101,6 +101,15 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
         views = ops.flat_grads(module, names, [p[n] for n in names]) if need_param_grads else {}
         if scope is not None:
             scope["flat"] = module.__dict__["_flat_grads"][-1]
+    return views, acc
+
+
+def backward_classifier(module, p, sv, dout, need_param_grads, st=None):
+    """Backward of the classifier (model.py:61-65) of one pass: fills classifier.* gradients, returns the state the
+    feature-stack half needs (incl. g = d LeakyReLU(BN(y_last)) in NHWC).  The data-parallel engine runs this half of both
+    passes first, so that the classifier bucket (75.5 MB) can be all-reduced while the feature stack's backward runs."""
+    views, acc = _grad_views(module, p, need_param_grads)
+    grads = {}
 
     def G(name):
         t = views[name]
@@ -118,6 +127,19 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
     last = sv["layers"][-1]
     B, H, W, C = last["y"].shape
     g = ops.linear_dgrad(dh1, p["classifier.0.weight"], nhwc=(C, H * W)).view(B, H, W, C)   # d LReLU(BN(y_last)) in NHWC
+    return {"views": views, "acc": acc, "grads": grads, "g": g}
+
+
+def backward_features(module, p, sv, st, need_param_grads, need_dx):
+    """Backward of the feature stack (model.py:30-59) of one pass, continuing from backward_classifier's state."""
+    views, acc, grads, g = st["views"], st["acc"], st["grads"], st["g"]
+
+    def G(name):
+        t = views[name]
+        grads[name] = t
+        return t
+
+    wg = need_param_grads
     dx = None
     wd, ws2 = sv["wd"], sv["ws2"]               # packed (or re-used) by the forward
     part = None                      # BN/activation backward partials of g, when the producing dgrad conv emitted them
@@ -164,6 +186,11 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
     if acc:
         grads = {}                   # already added into the first pass's buffer
     return grads, dx
+
+
+def backward(module, p, sv, dout, need_param_grads, need_dx):
+    st = backward_classifier(module, p, sv, dout, need_param_grads)
+    return backward_features(module, p, sv, st, need_param_grads, need_dx)
 
 
 class DiscriminatorFn(torch.autograd.Function):

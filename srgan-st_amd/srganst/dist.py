@@ -7,8 +7,9 @@ optimizer step, so parameters stay bit-identical across ranks.
 
 Payload: G = 1,547,350 fp32 (6.2 MB) after every G backward; D = 23,563,649 fp32 (94 MB) after
 every D backward.  xGMI is point-to-point, so collectives are per-link bound: few, large,
-flat buffers - G goes out as ONE all-reduce; D as two buckets (features 4.7 M / classifier
-18.9 M floats) so the first can start while the second is flattened.
+flat buffers - G goes out as ONE all-reduce; D as two buckets (classifier 18.9 M / features 4.7 M
+floats).  engine.TrainEngine overlaps them with compute: G's message travels under the discriminator step's forward,
+the classifier bucket under the feature stack's backward (AsyncAllReduce; the collectives run on RCCL's own stream).
 """
 from __future__ import annotations
 
@@ -104,6 +105,40 @@ def allreduce_module_grads(module, pg=None, buckets: int = 1, force: bool = Fals
         h.wait()
         if world > 1 and not avg:
             sl.mul_(1.0 / world)
+
+
+class AsyncAllReduce:
+    """One in-flight mean-all-reduce of a flat fp32 slice: issued on the process group's own stream (RCCL: a communication
+    stream next to the compute stream, so kernels launched after start() overlap it), joined by wait().
+    `force` issues the collective with a single rank too (exercises RCCL in tests); without a process group it is a no-op."""
+
+    def __init__(self, flat, pg=None, force: bool = False):
+        self.flat, self.pg, self.h = flat, pg, None
+        self.world = world_size(pg)
+        self.scale = False
+        if flat is None or (self.world == 1 and not (force and td.is_available() and td.is_initialized())):
+            return
+        avg = td.get_backend(pg) == "nccl" and hasattr(td.ReduceOp, "AVG")
+        self.h = td.all_reduce(flat, op=td.ReduceOp.AVG if avg else td.ReduceOp.SUM, group=pg, async_op=True)
+        self.scale = self.world > 1 and not avg
+
+    def wait(self):
+        if self.h is not None:
+            self.h.wait()
+            if self.scale:
+                self.flat.mul_(1.0 / self.world)
+            self.h = None
+
+
+def module_flat_grad(module):
+    """The flat buffer the module's parameter gradients are views of (srganst graphs leave them that way), or None."""
+    ps = [p for p in module.parameters() if p.grad is not None]
+    for cand in reversed(module.__dict__.get("_flat_grads", [])):
+        lo, hi = cand.data_ptr(), cand.data_ptr() + cand.numel() * 4
+        if ps and all(lo <= p.grad.data_ptr() < hi and p.grad.is_contiguous() for p in ps) and \
+                sum((p.grad.numel() + 15) // 16 * 16 for p in ps) == cand.numel():
+            return cand
+    return None
 
 
 def broadcast_module(module, src: int = 0, pg=None) -> None:

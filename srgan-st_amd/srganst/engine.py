@@ -208,7 +208,7 @@ class TrainEngine:
     """reference train.py:16-164 without loaders / logging / validation around the step."""
 
     def __init__(self, config, generator, discriminator, use_graph=None, process_group=None, adam_capturable=None,
-                 force_dp=False):
+                 force_dp=False, overlap_comm=None):
         from .loss import BCEWithLogitsLoss
         self.config = config
         self.G, self.D = generator, discriminator
@@ -235,15 +235,25 @@ class TrainEngine:
         # A captured graph bakes in the tensors that exist at capture time (D's graph reads the generator graph's static `sr`):
         # a mixed eager / graph state would replay on stale buffers, so ONE failed capture sends the whole engine back to eager.
         f = self._drop_graphs
+        # Data parallel with overlap (default): the discriminator half runs without autograd as [forward of both passes +
+        # classifier backward] -> classifier bucket on the wire -> [feature-stack backward] -> feature bucket; the
+        # generator's message travels under the first of those graphs.  overlap_comm=False: the round-1 schedule
+        # ([fwd+bwd] -> all-reduce -> wait -> [Adam] per network); both give bit-identical parameters (tests/test_dp_gpu.py).
+        self.overlap = self.dp and (config.DIST.OVERLAP_COMM if overlap_comm is None else overlap_comm)
+        self._d_a = self._d_b = None
         if self.dp:
             self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self.g_opt.step, enabled=g, on_fail=f)
             self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self._d_step, enabled=g, on_fail=f)
+            if self.overlap:
+                self._d_fb = None
+                self._d_a = _GraphedStep(self._d_fwd_cls, enabled=g, on_fail=f)
+                self._d_b = _GraphedStep(self._d_features, enabled=g, on_fail=f)
         else:
             self._g_fb, self._g_op = _GraphedStep(self._g_full, enabled=g, on_fail=f), None
             self._d_fb, self._d_op = _GraphedStep(self._d_full, enabled=g, on_fail=f), None
 
     def _steps(self):
-        return [s for s in (self._g_fb, self._g_op, self._d_fb, self._d_op) if s is not None]
+        return [s for s in (self._g_fb, self._g_op, self._d_fb, self._d_a, self._d_b, self._d_op) if s is not None]
 
     def _drop_graphs(self):
         for s in self._steps():
@@ -293,6 +303,44 @@ class TrainEngine:
         self.d_loss, self.pred_gt, self.pred_sr = d_loss.detach(), pred_gt.detach(), pred_sr.detach()
         return self.d_loss
 
+    # -- discriminator half without autograd, in two parts (data-parallel overlap).  Same kernels with the same arguments as
+    # the autograd path above, in an order that keeps every parameter's accumulation order (autograd runs the D(sr) pass
+    # before the D(gt) pass: loss_fake was recorded last), so the gradients are bit-identical.
+    def _d_fwd_cls(self):
+        from . import disc_graph, ops
+        D = self.D
+        for p in D.parameters():
+            p.requires_grad = True
+        self.d_opt.zero_grad(set_to_none=True)
+        names = [n for n, _ in D.named_parameters()]
+        pd = dict(zip(names, [t.detach() for t in D.parameters()]))
+        pred_gt, sv_gt = disc_graph.forward(D, self.gt, pd, True, True)
+        loss_real, dl_gt = ops.bce_logits(pred_gt, self.real, want_loss=True, want_grad=True)
+        pred_sr, sv_sr = disc_graph.forward(D, self.sr, pd, True, True)
+        loss_fake, dl_sr = ops.bce_logits(pred_sr, self.fake, want_loss=True, want_grad=True)
+        self.d_loss, self.pred_gt, self.pred_sr = loss_real + loss_fake, pred_gt, pred_sr
+        D.__dict__["_grad_accum"] = {"flat": None}
+        try:
+            st_sr = disc_graph.backward_classifier(D, pd, sv_sr, dl_sr, True)
+            st_gt = disc_graph.backward_classifier(D, pd, sv_gt, dl_gt, True)
+        finally:
+            D.__dict__.pop("_grad_accum", None)
+        self._d_state = (pd, sv_sr, st_sr, sv_gt, st_gt)
+        flat = D.__dict__["_flat_grads"][-1]
+        plist = [pd[n] for n in names]
+        offs, total = ops.flat_layout(plist)
+        cut = offs[names.index("classifier.0.weight")]          # features.* come first in the reference's parameter order
+        self._d_flat, self._d_buckets = flat, (flat[cut:total], flat[:cut])
+        return self.d_loss
+
+    def _d_features(self):
+        from . import disc_graph
+        pd, sv_sr, st_sr, sv_gt, st_gt = self._d_state
+        grads, _ = disc_graph.backward_features(self.D, pd, sv_sr, st_sr, True, False)
+        disc_graph.backward_features(self.D, pd, sv_gt, st_gt, True, False)
+        for n, p in self.D.named_parameters():
+            p.grad = grads[n]
+
     def _d_step(self):
         self.d_opt.step()
         self.D.__dict__["_packs_fresh"] = False      # weights changed
@@ -304,11 +352,35 @@ class TrainEngine:
 
     def close(self):
         """See WarmupEngine.close."""
-        self._g_fb = self._g_op = self._d_fb = self._d_op = None
+        self._g_fb = self._g_op = self._d_fb = self._d_op = self._d_a = self._d_b = None
+        self._d_state = self._d_flat = self._d_buckets = None
         self.gt = self.lr = self.sr = None
+
+    def _step_overlapped(self):
+        """Data-parallel iteration with the collectives hidden behind compute (see __init__)."""
+        self._g_fb()
+        ar_g = sdist.AsyncAllReduce(sdist.module_flat_grad(self.G), self.pg, force=True)      # travels under the D forward
+        did_d = self.batch_num % self.config.SOLVER.D_UPDATE_INTERVAL == 0
+        if did_d:
+            self._d_a()
+            ar_c = sdist.AsyncAllReduce(self._d_buckets[0], self.pg, force=True)              # classifier: 75.5 MB, under the feature backward
+            self._d_b()
+            ar_f = sdist.AsyncAllReduce(self._d_buckets[1], self.pg, force=True)
+        if ar_g.flat is None:                                    # gradients not in one flat buffer: the generic path
+            sdist.allreduce_module_grads(self.G, self.pg, force=True)
+        ar_g.wait()
+        self._g_op()
+        if did_d:
+            ar_c.wait()
+            ar_f.wait()
+            self._d_op()
+        self.batch_num += 1
+        return self.loss_values, (self.d_loss if did_d else None)
 
     def step(self, gt, lr):
         _load_inputs(self, gt, lr)
+        if self.overlap:
+            return self._step_overlapped()
         self._g_fb()
         if self.dp:
             sdist.allreduce_module_grads(self.G, self.pg, force=True)

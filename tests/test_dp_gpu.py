@@ -130,19 +130,22 @@ def _nccl_worker(port, q):
     # the full G + D step (train.py:100-164): [G fwd+bwd graph] -> all-reduce -> [G Adam] -> [D fwd+bwd graph] -> 2-bucket all-reduce -> [D Adam]
     from srganst.engine import TrainEngine
     from srganst.model import Discriminator
-    for force_dp in (False, True):
+    # single graphs / split graphs with blocking collectives (round-1 schedule) / overlapped schedule (default): the two D
+    # buckets and G's message are in flight on RCCL's stream while the next graphs run
+    for force_dp, overlap in ((False, False), (True, False), (True, True)):
         cfg, G = _make(seed=6)
         cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
         cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
         cfg.SOLVER.D_UPDATE_INTERVAL = 1
         torch.manual_seed(7)
         D = Discriminator(cfg).to("cuda:0").train()
-        eng = TrainEngine(cfg, G, D, use_graph=True, adam_capturable=True, force_dp=force_dp)
+        eng = TrainEngine(cfg, G, D, use_graph=True, adam_capturable=True, force_dp=force_dp, overlap_comm=overlap)
+        assert eng.overlap == overlap
         for step in range(4):
             g = torch.Generator().manual_seed(50 + step)           # the discriminator is fixed to 96 x 96 inputs (model.py:31-34)
             eng.step(torch.rand(2, 3, 96, 96, generator=g).cuda(), torch.rand(2, 3, 24, 24, generator=g).cuda())
         torch.cuda.synchronize()
-        assert eng._g_fb.graph is not None and eng._d_fb.graph is not None
+        assert eng.graph_active, "a hipGraph capture fell back to eager next to a live RCCL communicator"
         sd = {"G." + k: v.cpu().numpy() for k, v in G.state_dict().items()}
         sd.update({"D." + k: v.cpu().numpy() for k, v in D.state_dict().items()})
         out.append(sd)
@@ -158,10 +161,69 @@ def test_graph_capture_next_to_rccl_communicator():
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
     p.start()
-    a, b, c, d = q.get(timeout=300)
+    a, b, c, d, e = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0
     for k in a:
         assert (a[k] == b[k]).all(), k
     for k in c:
         assert (c[k] == d[k]).all(), k
+        assert (c[k] == e[k]).all(), k           # overlapped collectives: bit-identical to the single-graph step
+
+
+def _train_worker(rank, world, port, overlap, q):
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "srgan-st_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from srganst import dist as sdist
+    from srganst.engine import TrainEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator
+    sdist.init_from_env("gloo")
+    cfg, G = _make(seed=3 + rank)
+    cfg.MODEL.D_N_CHANNEL = 8
+    cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+    cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+    cfg.SOLVER.D_UPDATE_INTERVAL = 1
+    torch.manual_seed(11 + rank)
+    D = Discriminator(cfg).cuda().train()
+    sdist.broadcast_module(G)
+    sdist.broadcast_module(D)
+    eng = TrainEngine(cfg, G, D, use_graph=True, adam_capturable=True, overlap_comm=overlap)
+    assert eng.world == 2 and eng.overlap == overlap
+    for step in range(4):
+        g = torch.Generator().manual_seed(1000 * rank + step)
+        eng.step(torch.rand(2, 3, 96, 96, generator=g).cuda(), torch.rand(2, 3, 24, 24, generator=g).cuda())
+    torch.cuda.synchronize()
+    assert eng.graph_active
+    sd = {"G." + k: v.cpu().numpy() for k, v in G.state_dict().items()}
+    sd.update({"D." + k: v.cpu().numpy() for k, v in D.state_dict().items()})
+    q.put((rank, sd))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_dp_world2_overlapped_schedule_is_bit_identical():
+    """Full G + D iteration on 2 ranks (gloo carries the collectives): the overlapped schedule - G's message under the D forward,
+    classifier bucket under the feature-stack backward, D half without autograd - gives bit for bit the parameters of the blocking
+    schedule, identical on both ranks; BatchNorm buffers stay rank-local."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for overlap in (False, True):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_train_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        out = dict(q.get(timeout=300) for _ in procs)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        res[overlap] = out
+    for k in res[True][0]:
+        for r in (0, 1):
+            assert (res[True][r][k] == res[False][r][k]).all(), (k, r)
+        if "running" not in k and "num_batches" not in k:
+            assert (res[True][0][k] == res[True][1][k]).all(), k
+    assert not (res[True][0]["D.features.3.running_mean"] == res[True][1]["D.features.3.running_mean"]).all()
