@@ -15,12 +15,17 @@
 //     K loop) and the weight fragments come through a 9-deep register ring that is refilled one half stage ahead - the
 //     K loop is fully unrolled (18 chunks per wave and 64-channel block: wave w owns k-steps {2w, 2w+1} of every tap), all
 //     LDS / weight offsets are immediates;
+//   * the 4 waves split K by input channel and every wave stages ITS OWN 16-channel slice of the patch into a wave-private LDS
+//     region: no workgroup barrier inside a unit's stage loop, the waves drift freely and only meet at the end of a unit for
+//     the K-partial reduction (two barriers); after it wave w owns channels 8w..8w+7 of the tile for all 32 pixels, so bias,
+//     store, BatchNorm statistics and backward partials are wave-local (DPP row sums, no LDS, no further barrier);
 //   * layers with few tiles split K over workgroups (fp32 partial slabs in a caller-provided workspace, summed in fixed order
 //     by pipe_reduce_kernel, which then runs the same epilogue): every launch offers >= 4 equal units per CU.
 // GEMM view, fragment layouts, packed weights (conv_common.h: packed_index) and the epilogue's arithmetic (bias, per-tile
 // BatchNorm statistics (sum, centred M2), BatchNorm/activation backward partials) are those of conv_fwd.hip.
 #include "conv_common.h"
 #include <cstdlib>
+#include <type_traits>
 #include "conv_epilogue.h"
 
 int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride);   // conv_band.hip: trunk shapes stay there
@@ -52,8 +57,10 @@ struct PipeGeom {
   static constexpr int PW = (TW - 1) * S + 3;
   static constexpr int PR = (TH - 1) * S + 3 + NB;
   static constexpr int NP = PW * PR;
-  static constexpr int NU = (NP + 15) / 16;                  // patch pixels per thread (16 threads x 16 B per pixel)
-  static constexpr int LDS_FLOATS = NP * LDSC > 4 * 32 * 33 ? NP * LDSC : 4 * 32 * 33;
+  static constexpr int NU = (NP + 15) / 16;                  // patch pixels per lane (4 lanes x 16 B = one pixel's 16-channel slice)
+  static constexpr int PS = 20;                              // floats per pixel in a wave's patch (16 channels + 4 pad: 16-B aligned rows)
+  static constexpr int WAVE_FLOATS = NP * PS;                // one wave's private patch
+  static constexpr int SCRATCH = 4 * 32 * 33;                // K-partial exchange at the end of a unit
 };
 
 // one stage = one 64-channel block of one tile's input patch (+ the matching weight block)
@@ -73,73 +80,63 @@ struct Stage {
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase))
 #define PIPE_WAIT(reg, n) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n))
 
-// Epilogue of one 32 px x 32 ch tile for thread (pixel p = tid >> 3, channels cq..cq+3 of block nf), v = conv result.
-// Contains workgroup barriers: call from all 256 threads.
+// sum over the 32 lanes of a wave half (lanes with equal lane >> 5): DPP row rotations + one cross-row exchange
+__device__ __forceinline__ float half_sum(float t) {
+  auto ror = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  t += ror(t, std::integral_constant<int, 0x128>{});   // row_ror:8
+  t += ror(t, std::integral_constant<int, 0x124>{});   // row_ror:4
+  t += ror(t, std::integral_constant<int, 0x122>{});   // row_ror:2
+  t += ror(t, std::integral_constant<int, 0x121>{});   // row_ror:1
+  t += __shfl_xor(t, 16, 64);
+  return t;
+}
+
+// Epilogue of one 32 px x 32 ch tile, wave-local: this lane holds v[j] = conv result of pixel px = lane & 31 of the tile,
+// channels c0 .. c0+3 (c0 = nf*32 + 8*wave + 4*(lane >> 5)).  No barriers, no LDS.
 template <int TW>
-__device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float (*sstat)[3][32], float v[4], int r0, int ox0, int nf, int mt,
-                                              int tid, int wave, int lane) {
+__device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float v[4], int r0, int ox0, int c0, int mt, int lane, bool first) {
   constexpr int TH = 32 / TW;
-  const int p = tid >> 3, cq = (tid & 7) * 4;
-  const int r = r0 + p / TW, ox = ox0 + p % TW;
-  const int n0 = nf * 32 + cq;
+  const int px = lane & 31;
+  const int r = r0 + px / TW, ox = ox0 + px % TW;
   const bool pix_ok = r < a.R && ox < a.Wo;
   if (a.bias) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n0);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] += bv[j];
   }
-  const size_t obase = ((size_t)r * a.Wo + ox) * a.Cout + n0;
+  const size_t obase = ((size_t)r * a.Wo + ox) * a.Cout + c0;
   if (pix_ok) *reinterpret_cast<f32x4*>(a.y + obase) = f32x4{v[0], v[1], v[2], v[3]};
   if (a.stats) {
+    // per-tile (sum, centred M2) per output channel over the tile's valid pixels (combined by bn_finalize with Chan's formula)
     const int nvalid = min(TH, a.R - r0) * min(TW, a.Wo - ox0);
-    float s1[4], m2[4];
+    f32x4 s1, m2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s1[j] = half_sum(pix_ok ? v[j] : 0.f);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float s = pix_ok ? v[j] : 0.f;
-      s += __shfl_xor(s, 8, 64);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      s1[j] = s;
+      const float mean = s1[j] / (float)nvalid;
+      const float d = pix_ok ? (v[j] - mean) : 0.f;
+      m2[j] = half_sum(d * d);
     }
-    if (lane < 8) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sstat[wave][0][lane * 4 + j] = s1[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float tot = sstat[0][0][cq + j] + sstat[1][0][cq + j] + sstat[2][0][cq + j] + sstat[3][0][cq + j];
-      const float mean = tot / (float)nvalid;
-      float d = pix_ok ? (v[j] - mean) : 0.f;
-      d = d * d;
-      d += __shfl_xor(d, 8, 64);
-      d += __shfl_xor(d, 16, 64);
-      d += __shfl_xor(d, 32, 64);
-      m2[j] = d;
-    }
-    if (lane < 8) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sstat[wave][1][lane * 4 + j] = m2[j];
-    }
-    __syncthreads();
-    if (tid < 32) {
-      const float tot = sstat[0][0][tid] + sstat[1][0][tid] + sstat[2][0][tid] + sstat[3][0][tid];
-      const float m2t = sstat[0][1][tid] + sstat[1][1][tid] + sstat[2][1][tid] + sstat[3][1][tid];
+    if (px == 0) {
       float* st = a.stats + (size_t)mt * 2 * a.Cout;
-      st[nf * 32 + tid] = tot;
-      st[a.Cout + nf * 32 + tid] = m2t;
-      if (tid == 0 && nf == 0) a.stats_cnt[mt] = (float)nvalid;
+      *reinterpret_cast<f32x4*>(st + c0) = s1;
+      *reinterpret_cast<f32x4*>(st + a.Cout + c0) = m2;
+      if (first) a.stats_cnt[mt] = (float)nvalid;
     }
   }
   if (a.epi_partial) {
+    // backward partials of the stored value g against the saved conv output epi_y (see conv_epilogue.h: Conv3Args)
     const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
-    float q[3][4];
     f32x4 yv = {0.f, 0.f, 0.f, 0.f}, es = {1.f, 1.f, 1.f, 1.f}, eh = {0.f, 0.f, 0.f, 0.f};
     if (pix_ok) yv = *reinterpret_cast<const f32x4*>(a.epi_y + obase);
     if (a.epi_scale) {
-      es = *reinterpret_cast<const f32x4*>(a.epi_scale + n0);
-      eh = *reinterpret_cast<const f32x4*>(a.epi_shift + n0);
+      es = *reinterpret_cast<const f32x4*>(a.epi_scale + c0);
+      eh = *reinterpret_cast<const f32x4*>(a.epi_shift + c0);
     }
+    f32x4 q[3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float g = pix_ok ? v[j] : 0.f;
@@ -149,31 +146,13 @@ __device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float (*sstat)[
         q2 = g * fminf(z, 0.f);
         gz = z > 0.f ? g : g * eslope;
       }
-      q[0][j] = gz;
-      q[1][j] = gz * yv[j];
-      q[2][j] = q2;
+      q[0][j] = half_sum(gz);
+      q[1][j] = half_sum(gz * yv[j]);
+      q[2][j] = half_sum(q2);
     }
+    if (px == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = q[k][j];
-        t += __shfl_xor(t, 8, 64);
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        q[k][j] = t;
-      }
-    __syncthreads();
-    if (lane < 8) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sstat[wave][k][lane * 4 + j] = q[k][j];
-    }
-    __syncthreads();
-    if (tid < 96) {
-      const int k = tid >> 5, c = tid & 31;
-      a.epi_partial[((size_t)mt * 3 + k) * a.Cout + nf * 32 + c] = sstat[0][k][c] + sstat[1][k][c] + sstat[2][k][c] + sstat[3][k][c];
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<f32x4*>(a.epi_partial + ((size_t)mt * 3 + k) * a.Cout + c0) = q[k];
     }
   }
 }
@@ -182,15 +161,17 @@ template <int S, int TW>
 __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(PipeArgs a) {
   using G = PipeGeom<S, TW>;
   constexpr int PW = G::PW, NP = G::NP, NU = G::NU, NB = G::NB;
-  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
-  __shared__ float sstat[4][3][32];
+  constexpr int PS = G::PS;
+  __shared__ __attribute__((aligned(16))) float patch[4 * G::WAVE_FLOATS];   // [wave][patch pixel][16 channels + pad]
+  __shared__ __attribute__((aligned(16))) float scratch[G::SCRATCH];         // [wave][tile pixel 32][33]
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int nwg = gridDim.x;
   const int HV = a.H + 1;                                 // rows of one image in the virtual tall input (its top zero row + H)
   const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
-  const int c4 = (tid & 15) * 4;                          // this thread's channel quad inside a 64-channel block (staging)
-  const int p0 = tid >> 4;                                // its first patch pixel
+  const int c4 = wave * 16 + (lane & 3) * 4;              // this lane's channel quad inside a 64-channel block: its wave's slice
+  const int p0 = lane >> 2;                               // its first patch pixel (4 lanes per pixel)
+  float* const lds = patch + wave * G::WAVE_FLOATS;       // this wave's private patch
 
   // ---- unit / stage sequencing (all wave-uniform)
   int q = blockIdx.x;                                     // current unit
@@ -270,17 +251,17 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
         for (int j = 0; j < 4; ++j) t[j] = t[j] > 0.f ? t[j] : t[j] * slope;
       }
       if (!((okmask >> u) & 1u)) t = f32x4{0.f, 0.f, 0.f, 0.f};            // zero padding stays exactly zero
-      *reinterpret_cast<f32x4*>(&lds[p * LDSC + c4]) = t;
+      *reinterpret_cast<f32x4*>(&lds[p * PS + (lane & 3) * 4]) = t;
     }
   };
 
-  // ---- this lane's A-fragment base in the patch: pixel li of the tile (+ 4*lh channels, + this wave's two k-steps)
+  // ---- this lane's A-fragment base in its wave's patch: pixel li of the tile (+ 4*lh channels)
   auto lane_base = [&](int oy0_) {
     const int tr = li / TW, tc = li - tr * TW;
     int cross = 0;
 #pragma unroll
     for (int k = 1; k <= NB; ++k) cross += (oy0_ + tr >= k * a.Ho) ? 1 : 0;
-    return ((S * tr + cross) * PW + tc * S) * LDSC + 4 * lh + wave * 16;
+    return ((S * tr + cross) * PW + tc * S) * PS + 4 * lh;
   };
   int a_base = lane_base(oy0);
 
@@ -296,7 +277,6 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   stage_store();
-  __syncthreads();
 
   f32x16 acc;
 #pragma unroll
@@ -340,7 +320,7 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
         f32x4 an = av;
         if (i + 1 < 18) {
           const int t = (i + 1) >> 1;
-          an = *reinterpret_cast<const f32x4*>(ab + ((t / 3) * PW + (t % 3)) * LDSC + ((i + 1) & 1) * 8);
+          an = *reinterpret_cast<const f32x4*>(ab + ((t / 3) * PW + (t % 3)) * PS + ((i + 1) & 1) * 8);
         }
         if (i == 0 || i >= 10) PIPE_WAIT(ring[i % PIPE_RING], 8); else PIPE_WAIT(ring[i % PIPE_RING], 8 + NS);
         const f32x4 bv = ring[i % PIPE_RING];
@@ -353,66 +333,63 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();                       // every wave is done reading the patch
-
     if (unit_end && (a.dbg & 2)) {
       if (acc[0] == 12345.f) a.y[0] = acc[0];
       if (!more) return;
       a_base = lane_base(n_oy0);
     } else if (unit_end) {
-      // ---- the 4 waves' K-partials -> LDS -> one value quad per thread
+      // ---- the 4 waves' K-partials -> LDS; afterwards wave w owns channels 8w .. 8w+7 of the tile for all 32 pixels
+      __syncthreads();                     // everyone has read the previous unit's partials
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        lds[(wave * 32 + row) * 33 + li] = acc[r];
+        scratch[(wave * 32 + row) * 33 + li] = acc[r];
         acc[r] = 0.f;
       }
       __syncthreads();
-      const int p = tid >> 3, cq = (tid & 7) * 4;
+      const int cl = 8 * wave + 4 * lh;    // first of this lane's 4 channels inside the 32-channel block
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float s = lds[(0 * 32 + p) * 33 + cq + j];
-        s += lds[(1 * 32 + p) * 33 + cq + j];
-        s += lds[(2 * 32 + p) * 33 + cq + j];
-        s += lds[(3 * 32 + p) * 33 + cq + j];
-        v[j] = s;
+        float t = scratch[(0 * 32 + li) * 33 + cl + j];
+        t += scratch[(1 * 32 + li) * 33 + cl + j];
+        t += scratch[(2 * 32 + li) * 33 + cl + j];
+        t += scratch[(3 * 32 + li) * 33 + cl + j];
+        v[j] = t;
       }
       if (a.ksplit > 1) {
         const int tile = nf * a.n_mt + mt;
         const int part = cb / a.cb_per;
-        *reinterpret_cast<f32x4*>(a.ws + ((size_t)part * a.total_tiles + tile) * 1024 + p * 32 + cq) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(a.ws + ((size_t)part * a.total_tiles + tile) * 1024 + li * 32 + cl) = f32x4{v[0], v[1], v[2], v[3]};
       } else {
-        pipe_epilogue<TW>(a, sstat, v, r0, ox0, nf, mt, tid, wave, lane);
+        pipe_epilogue<TW>(a, v, r0, ox0, nf * 32 + cl, mt, lane, nf == 0 && wave == 0);
       }
-      __syncthreads();                     // scratch (overlays the patch) is free again
       if (!more) return;
       a_base = lane_base(n_oy0);
     }
-    stage_store();                         // next stage's patch: registers -> LDS
-    __syncthreads();
+    stage_store();                         // next stage's patch slice: registers -> this wave's LDS region (LDS ops of a wave
+                                           // complete in order: the K loop's reads above are done before these writes land)
     q = n_q; mt = n_mt; nf = n_nf; r0 = n_r0; ox0 = n_ox0; oy0 = n_oy0; cb = n_cb; cb_end = n_cb_end;
     cur = nxt;
   }
 }
 
-// Split-K: sum the partial slabs of one tile in fixed order, then the ordinary epilogue.
+// Split-K: sum the partial slabs of one tile in fixed order, then the ordinary (wave-local) epilogue.
 template <int TW>
 __global__ __launch_bounds__(CONV_NT) void pipe_reduce_kernel(PipeArgs a) {
-  __shared__ float sstat[4][3][32];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = blockIdx.x;
   const int nf = tile / a.n_mt, mt = tile - nf * a.n_mt;
   const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
-  const int p = tid >> 3, cq = (tid & 7) * 4;
-  f32x4 s = *reinterpret_cast<const f32x4*>(a.ws + (size_t)tile * 1024 + p * 32 + cq);
+  const int li = lane & 31, cl = 8 * wave + 4 * (lane >> 5);
+  f32x4 s = *reinterpret_cast<const f32x4*>(a.ws + (size_t)tile * 1024 + li * 32 + cl);
   for (int k = 1; k < a.ksplit; ++k) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(a.ws + ((size_t)k * a.total_tiles + tile) * 1024 + p * 32 + cq);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(a.ws + ((size_t)k * a.total_tiles + tile) * 1024 + li * 32 + cl);
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] += t[j];
   }
   float v[4] = {s[0], s[1], s[2], s[3]};
-  pipe_epilogue<TW>(a, sstat, v, ty * (32 / TW), tx * TW, nf, mt, tid, wave, lane);
+  pipe_epilogue<TW>(a, v, ty * (32 / TW), tx * TW, nf * 32 + cl, mt, lane, nf == 0 && wave == 0);
 }
 
 struct PipePlan {
