@@ -220,3 +220,45 @@ def test_generator_vs_oracle_hr192():
     assert abs(loss.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
     for n, p in G.named_parameters():
         assert_fp64_truth(n, p.grad.cpu(), g32[n], g64[n])
+
+
+def test_accumulator_mode_run_to_run(capsys):
+    """What is promised about reproducibility at the full width (64 channels: the trunk runs conv_band_kernel in accumulator
+    mode, BatchNorm sums through hardware fp64 atomics, csrc/conv_epilogue.h: BandAcc).  The atomic adds commute but do not
+    associate: two runs of the same step may differ in the last bits of an fp64 sum (1e-16 relative), which can - rarely - move
+    an fp32 rounding of a BatchNorm mean / rstd.  ASSERTED: run-to-run differences of SR, every gradient and every BatchNorm buffer
+    stay below 1e-6 relative (three orders under the 1e-3 parity contract).  NOT asserted: bitwise equality (reported: it is
+    what is observed in practice; the partial-tile path, SST_ATOMIC_STATS=0, and every kernel outside the trunk are bitwise
+    reproducible by construction - fixed-order reductions, tests/test_discriminator_gpu.py::test_train_engine_graph_equals_eager)."""
+    from srganst.model import Generator
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst import ops
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(19)
+    gt = torch.rand(16, 3, 96, 96, generator=g).cuda()
+    lr = torch.rand(16, 3, 24, 24, generator=g).cuda()
+    assert ops.conv_acc_supported(16, 24, 24, 64, 64)
+    G0 = Generator(make_cfg(64, 4)).cuda()
+    sd0 = {k: v.clone() for k, v in G0.state_dict().items()}
+    runs = []
+    for _ in range(3):
+        G = Generator(make_cfg(64, 4)).cuda()
+        G.load_state_dict(sd0)
+        G.train()
+        mse, st = MSELoss(), StructureTensorLoss()
+        sr = G(lr)
+        (mse(sr, gt) + st(sr, gt) * (1 / 3)).backward()
+        out = {"sr": sr.detach().clone()}
+        out.update({"grad/" + n: p.grad.clone() for n, p in G.named_parameters()})
+        out.update({"buf/" + k: v.clone() for k, v in G.state_dict().items() if "running" in k})
+        runs.append(out)
+    worst, identical = 0.0, 0
+    for k in runs[0]:
+        for other in runs[1:]:
+            a, b = runs[0][k].double(), other[k].double()
+            d = float((a - b).norm() / a.norm().clamp_min(1e-30))
+            worst = max(worst, d)
+            identical += int(torch.equal(runs[0][k], other[k]))
+    with capsys.disabled():
+        print(f"\\n[accumulator mode, 3 runs] worst run-to-run difference {worst:.2e}; {identical} of {2 * len(runs[0])} tensor pairs bit-identical")
+    assert worst < 1e-6
