@@ -465,7 +465,11 @@ SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const f
   a.tiles_x = pl.tiles_x; a.n_mt = pl.n_mt; a.nfc = pl.nfc; a.total_tiles = pl.n_mt * pl.nfc; a.ncb = pl.ncb;
   a.ksplit = pl.ksplit; a.cb_per = pl.ncb / pl.ksplit; a.units = a.total_tiles * pl.ksplit;
   a.dbg = getenv("SST_PIPE_DBG") ? atoi(getenv("SST_PIPE_DBG")) : 0;     // ablation bits (tools/ablate_pipe.py): 1 no LDS staging writes, 2 no epilogue
-  const int wg_per_cu = stride == 1 ? 3 : 2;           // = the kernels' launch bounds (register-limited)
+  int wg_per_cu = stride == 1 ? 3 : 2;                 // = the kernels' launch bounds (register-limited)
+  if (const char* e = getenv("SST_PIPE_GPC")) {        // dev: fewer resident workgroups leave room for kernels of other streams
+    const int v = atoi(e);
+    if (v >= 1 && v < wg_per_cu) wg_per_cu = v;
+  }
   const int grid = a.units < wg_per_cu * PIPE_CUS ? a.units : wg_per_cu * PIPE_CUS;
   hipStream_t st = sst_stream(stream);
 #define SST_PIPE_LAUNCH(S_, TW_)                                                                  \

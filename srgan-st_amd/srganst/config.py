@@ -9,6 +9,8 @@ Differences, all additive:
 """
 from __future__ import annotations
 
+import os
+
 import copy
 
 import torch
@@ -103,6 +105,10 @@ class Config:
         self.KERNEL = dotdict()
         self.KERNEL.USE_GRAPH = True        # capture the train step into a hipGraph
         self.KERNEL.SYNC_LOSS_EVERY_STEP = False  # reference does .item() per criterion per step (train.py:141)
+        # discriminator step: D(gt) and D(sr) passes as two parallel branches of the graph (engine.TrainEngine._d_two_stream)
+        self.KERNEL.D_TWO_STREAMS = os.environ.get("SST_D_TWO_STREAMS", "0") != "0"
+        # the discriminator step beside the generator's backward, whole iteration = one graph (engine.TrainEngine._iter_gd)
+        self.KERNEL.OVERLAP_GD = os.environ.get("SST_OVERLAP_GD", "1") != "0"
         self.KERNEL.LR_ON_DEVICE = False    # True: the LR batch is synthesised from the GT batch on the GPU (sst_bicubic, same
                                             # values as dataset.py:28 on the 1/255 grid) instead of taking the loader's copy
 

@@ -50,10 +50,14 @@ def _packs(module, p, with_dgrad):
     return wp, wd, ws2
 
 
-def forward(module, x, p, training, need_grad=False):
+def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook=None):
+    """bump_counters=False: the caller has already added this pass to num_batches_tracked (two passes on two streams must
+    not race on the counters).  bn_hook(li, when) is called right before ("pre") / after ("post") each train-mode
+    bn_finalize - the only kernels of a forward that write shared state (running statistics): a caller that runs two passes
+    concurrently orders them there."""
     sv = {"layers": []}
     wp, sv["wd"], sv["ws2"] = _packs(module, p, need_grad)
-    if training:
+    if training and bump_counters:
         ops.flatten_bn_counters(module).add_(1)
     x3 = ops.transpose(x.contiguous(), to_nchw=False)
     h, scale, shift, act = x3, None, None, 0
@@ -68,7 +72,11 @@ def forward(module, x, p, training, need_grad=False):
             bn = module.features[bi]
             g, b = p[f"features.{bi}.weight"], p[f"features.{bi}.bias"]
             if training:
+                if bn_hook is not None:
+                    bn_hook(len(sv["layers"]), "pre")
                 mean, rstd, scale, shift = ops.bn_finalize(st, cnt, g, b, bn.running_mean, bn.running_var)
+                if bn_hook is not None:
+                    bn_hook(len(sv["layers"]), "post")
                 rec["mean"], rec["rstd"] = mean, rstd
             else:
                 scale, shift = ops.bn_eval_affine(g, b, bn.running_mean, bn.running_var)

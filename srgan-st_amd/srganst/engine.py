@@ -241,6 +241,8 @@ class TrainEngine:
         # ([fwd+bwd] -> all-reduce -> wait -> [Adam] per network); both give bit-identical parameters (tests/test_dp_gpu.py).
         self.overlap = self.dp and (config.DIST.OVERLAP_COMM if overlap_comm is None else overlap_comm)
         self._d_a = self._d_b = None
+        self._side = self._side_d = None
+        self._it = None
         if self.dp:
             self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self.g_opt.step, enabled=g, on_fail=f)
             self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self._d_step, enabled=g, on_fail=f)
@@ -249,10 +251,16 @@ class TrainEngine:
                 self._d_a = _GraphedStep(self._d_fwd_cls, enabled=g, on_fail=f)
                 self._d_b = _GraphedStep(self._d_features, enabled=g, on_fail=f)
         else:
+            two = bool(getattr(config.KERNEL, "D_TWO_STREAMS", False))
             self._g_fb, self._g_op = _GraphedStep(self._g_full, enabled=g, on_fail=f), None
-            self._d_fb, self._d_op = _GraphedStep(self._d_full, enabled=g, on_fail=f), None
+            self._d_fb, self._d_op = _GraphedStep(self._d_two_stream_full if two else self._d_full, enabled=g, on_fail=f), None
+            # whole iteration as ONE graph: the discriminator step runs beside the generator's backward (see _iter_gd)
+            if bool(getattr(config.KERNEL, "OVERLAP_GD", False)):
+                self._it = _GraphedStep(self._iter_gd, enabled=g, on_fail=f)
 
     def _steps(self):
+        if self._it is not None:               # merged iterations; generator-only graph between them when D is updated every n-th step
+            return [self._it] + ([self._g_fb] if self.config.SOLVER.D_UPDATE_INTERVAL > 1 else [])
         return [s for s in (self._g_fb, self._g_op, self._d_fb, self._d_a, self._d_b, self._d_op) if s is not None]
 
     def _drop_graphs(self):
@@ -341,6 +349,95 @@ class TrainEngine:
         for n, p in self.D.named_parameters():
             p.grad = grads[n]
 
+    # -- discriminator half with its two passes on two streams (under capture: two parallel branches of the hipGraph).  D(gt) and
+    # D(sr.detach()) share nothing but the weights (read-only here), the BatchNorm running statistics (ordered pass by pass at
+    # every bn_finalize, so the buffers move exactly as in the sequential order gt -> sr) and the gradient buffer (each pass
+    # writes its own flat buffer; they are added afterwards: fl(a + b), bit for bit what the accumulate flag does).  The many
+    # latency-bound launches of one pass (BatchNorm finalize / backward reduce / apply, 1-4 workgroups each) then run beside
+    # the other pass's kernels instead of in front of them.  Measured: 6.49 -> 6.18 ms per iteration; superseded by _iter_gd
+    # (5.92 ms), kept as KERNEL.D_TWO_STREAMS for engines that do not merge the iteration.
+    def _d_two_stream(self):
+        from . import disc_graph, ops
+        D = self.D
+        for p in D.parameters():
+            p.requires_grad = True
+        self.d_opt.zero_grad(set_to_none=True)
+        names = [n for n, _ in D.named_parameters()]
+        pd = dict(zip(names, [t.detach() for t in D.parameters()]))
+        ops.flatten_bn_counters(D).add_(2)
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+        ev = {}
+
+        def hook_a(li, when):
+            if when == "post":
+                e = torch.cuda.Event()
+                e.record(main)
+                ev[li] = e
+
+        def hook_b(li, when):
+            if when == "pre":
+                side.wait_event(ev[li])
+
+        pred_gt, sv_gt = disc_graph.forward(D, self.gt, pd, True, True, bump_counters=False, bn_hook=hook_a)   # packs weights if needed
+        loss_real, dl_gt = ops.bce_logits(pred_gt, self.real, want_loss=True, want_grad=True)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pred_sr, sv_sr = disc_graph.forward(D, self.sr, pd, True, True, bump_counters=False, bn_hook=hook_b)
+            loss_fake, dl_sr = ops.bce_logits(pred_sr, self.fake, want_loss=True, want_grad=True)
+            st_sr = disc_graph.backward_classifier(D, pd, sv_sr, dl_sr, True)
+            g_sr, _ = disc_graph.backward_features(D, pd, sv_sr, st_sr, True, False)
+            flat_sr = D.__dict__["_flat_grads"][-1]
+        st_gt = disc_graph.backward_classifier(D, pd, sv_gt, dl_gt, True)
+        g_gt, _ = disc_graph.backward_features(D, pd, sv_gt, st_gt, True, False)
+        flat_gt = D.__dict__["_flat_grads"][-1]
+        main.wait_stream(side)
+        flat_sr.add_(flat_gt)                 # autograd order of the sequential path: the D(sr) pass writes, the D(gt) pass accumulates
+        self.d_loss, self.pred_gt, self.pred_sr = loss_real + loss_fake, pred_gt, pred_sr
+        lst = D.__dict__["_flat_grads"]
+        lst[:] = [t for t in lst if t is not flat_sr] + [flat_sr]      # the buffer that holds p.grad is the newest one (FlatAdam / dist look there first)
+        for n, p in D.named_parameters():
+            p.grad = g_sr[n]
+        return self.d_loss
+
+    # -- the whole iteration (train.py:125-164) as one launch DAG: the discriminator step needs nothing of the generator's
+    # backward (only sr, D's weights and - for the order of the running statistics - the generator step's D(sr) FORWARD), so it
+    # starts as soon as the generator step's forward is complete and runs on side streams beside the generator's backward +
+    # Adam: the trunk's backward is a chain of ~70 short launches that leave most of the chip idle.  D's Adam comes after the
+    # join (the generator's backward through D still reads D's weights).  Same kernels, same arguments, same order per tensor:
+    # bit-identical to the sequential schedule.
+    def _iter_gd(self):
+        cfg = self.config
+        for p in self.D.parameters():
+            p.requires_grad = False
+        self.g_opt.zero_grad(set_to_none=True)
+        self.D.__dict__["_packs_fresh"] = False
+        sr = self.G(self.lr)
+        total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
+                                       adversarial=lambda crit: crit(self.D(sr), self.real))
+        self.sr = sr.detach()
+        main = torch.cuda.current_stream()
+        if self._side_d is None:
+            self._side_d = torch.cuda.Stream()
+        self._side_d.wait_stream(main)
+        with torch.cuda.stream(self._side_d):   # both passes on ONE side stream: a third concurrent branch (the two passes on two
+            self._d_fwd_cls()                   # streams, as _d_two_stream does on its own) crashed hipStreamEndCapture (ROCm 7.2)
+            self._d_features()
+        with torch.autograd.set_multithreading_enabled(False):      # backward on this thread: one thread feeds the open capture
+            total.backward(_one(total))
+        self.loss_values = vals
+        self.g_opt.step()
+        main.wait_stream(self._side_d)
+        self._d_step()
+        return vals
+
+    def _d_two_stream_full(self):
+        v = self._d_two_stream()
+        self._d_step()
+        return v
+
     def _d_step(self):
         self.d_opt.step()
         self.D.__dict__["_packs_fresh"] = False      # weights changed
@@ -352,7 +449,7 @@ class TrainEngine:
 
     def close(self):
         """See WarmupEngine.close."""
-        self._g_fb = self._g_op = self._d_fb = self._d_op = self._d_a = self._d_b = None
+        self._g_fb = self._g_op = self._d_fb = self._d_op = self._d_a = self._d_b = self._it = None
         self._d_state = self._d_flat = self._d_buckets = None
         self.gt = self.lr = self.sr = None
 
@@ -381,6 +478,11 @@ class TrainEngine:
         _load_inputs(self, gt, lr)
         if self.overlap:
             return self._step_overlapped()
+        if self._it is not None:
+            did_d = self.batch_num % self.config.SOLVER.D_UPDATE_INTERVAL == 0
+            (self._it if did_d else self._g_fb)()
+            self.batch_num += 1
+            return self.loss_values, (self.d_loss if did_d else None)
         self._g_fb()
         if self.dp:
             sdist.allreduce_module_grads(self.G, self.pg, force=True)

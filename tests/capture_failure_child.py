@@ -15,6 +15,9 @@ def make_cfg(ch, rcb, dch):
     return cfg
 
 
+INTERVAL = 2      # D updated every second iteration: the engine holds TWO graphs (merged G + D iteration, generator-only iteration)
+
+
 def run(use_graph, sabotage):
     from srganst.engine import TrainEngine
     from srganst.loss import MSELoss, StructureTensorLoss
@@ -24,10 +27,11 @@ def run(use_graph, sabotage):
     D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
     cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
     cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
-    cfg.SOLVER.D_UPDATE_INTERVAL = 1
+    cfg.SOLVER.D_UPDATE_INTERVAL = INTERVAL
     eng = TrainEngine(cfg, G, D, use_graph=use_graph, adam_capturable=True)
+    assert len(eng._steps()) == 2
     if sabotage:
-        step = eng._g_fb if sabotage == "g" else eng._d_fb
+        step = eng._g_fb if sabotage == "g" else eng._it       # "g": the generator-only graph, "d": the merged G + D iteration
         inner = step.fn
 
         def fn():
@@ -36,7 +40,7 @@ def run(use_graph, sabotage):
             return inner()
         step.fn = fn
     gen = torch.Generator().manual_seed(2)
-    for _ in range(6):
+    for _ in range(8):
         eng.step(torch.rand(4, 3, 96, 96, generator=gen).cuda(), torch.rand(4, 3, 24, 24, generator=gen).cuda())
     torch.cuda.synchronize()
     return eng, G.state_dict(), D.state_dict(), {k: v.item() for k, v in eng.loss_values.items()}

@@ -325,3 +325,42 @@ def test_train_engine_capture_failure_drops_every_graph(fail):
     r = subprocess.run([sys.executable, child, fail], capture_output=True, text=True, timeout=600)
     assert "FALLBACK-PARITY-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     assert "RECAPTURE-OK" in r.stdout and r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("interval", [1, 2])
+def test_train_engine_schedules_are_bit_identical(interval):
+    """The iteration's launch schedules (engine.TrainEngine): sequential [G step][D step] (round 1), the discriminator step's two
+    passes on two streams (KERNEL.D_TWO_STREAMS), and the default - whole iteration as ONE graph with the discriminator step beside
+    the generator's backward (KERNEL.OVERLAP_GD, _iter_gd).  Same kernels, same arguments, same order per tensor: parameters,
+    BatchNorm buffers (running statistics move in the order D(sr) of the G step, D(gt), D(sr)) and losses must be bit-identical,
+    eager and under hipGraph replay, with D updated every step and every second step."""
+    from srganst.engine import TrainEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+
+    def run(gd, two, use_graph):
+        cfg = make_cfg(16, 2, 8)
+        cfg.KERNEL.OVERLAP_GD, cfg.KERNEL.D_TWO_STREAMS = gd, two
+        torch.manual_seed(1)
+        D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
+        cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+        cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+        cfg.SOLVER.D_UPDATE_INTERVAL = interval
+        eng = TrainEngine(cfg, G, D, use_graph=use_graph, adam_capturable=True)
+        gen = torch.Generator().manual_seed(2)
+        for _ in range(8):
+            eng.step(torch.rand(4, 3, 96, 96, generator=gen).cuda(), torch.rand(4, 3, 24, 24, generator=gen).cuda())
+        torch.cuda.synchronize()
+        assert eng.graph_active == use_graph
+        sd = {"G." + k: v.clone() for k, v in G.state_dict().items()}
+        sd.update({"D." + k: v.clone() for k, v in D.state_dict().items()})
+        sd.update({"loss." + k: v.clone() for k, v in eng.loss_values.items()})
+        sd["d_loss"] = eng.d_loss.clone()
+        return sd
+
+    ref = run(False, False, False)                      # sequential, eager
+    assert int(ref["D.features.3.num_batches_tracked"]) == 8 + 2 * (8 // interval)
+    for gd, two, use_graph in ((False, False, True), (False, True, False), (False, True, True), (True, False, False), (True, False, True)):
+        out = run(gd, two, use_graph)
+        for k in ref:
+            assert torch.equal(ref[k], out[k]), (gd, two, use_graph, k)
