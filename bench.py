@@ -16,6 +16,7 @@ and then exits 3.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -136,6 +137,28 @@ def kernel_roofline(workload, device, hr, B):
         rows[name] = {"bound": "hbm", "launches_per_step": len(calls), "avg_launch_us": t / len(calls) * 1e6, "gbs": nbytes / t / 1e9,
                       "frac": nbytes / t / 1e9 / PEAK_HBM_GBS, "ms_per_step": t * 1e3, "bytes_per_launch": nbytes / len(calls)}
     eng.close()
+    # One kernel template = one family: rocprofv3 lists the instantiations of a template separately (conv_pipe_kernel<1, 8>,
+    # <1, 4>, <2, 8> ...: stride and tile width; conv_band_kernel<3, true> / <3, false> are already merged by the library's
+    # label).  A family row = all launches of the template's instantiations: sum of their FLOPs (bytes) over the sum of their times.
+    fams = {}
+    for name, r_ in rows.items():
+        fam = re.sub(r"<[^>]*>", "", name.split("+")[0]).replace("(grouped)", "")
+        fams.setdefault(fam, []).append(name)
+    for fam, members in fams.items():
+        if len(members) < 2:
+            continue
+        t = sum(rows[m]["ms_per_step"] for m in members) * 1e-3
+        n = sum(rows[m]["launches_per_step"] for m in members)
+        if rows[members[0]]["bound"] == "mfma":
+            fl = sum(rows[m]["flop_per_launch"] * rows[m]["launches_per_step"] for m in members)
+            rows[fam] = {"bound": "mfma", "launches_per_step": n, "avg_launch_us": t / n * 1e6, "tflops": fl / t / 1e12,
+                         "frac": fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "ms_per_step": t * 1e3, "flop_per_launch": fl / n,
+                         "instantiations": sorted(members)}
+        else:
+            nb = sum(rows[m]["bytes_per_launch"] * rows[m]["launches_per_step"] for m in members)
+            rows[fam] = {"bound": "hbm", "launches_per_step": n, "avg_launch_us": t / n * 1e6, "gbs": nb / t / 1e9,
+                         "frac": nb / t / 1e9 / PEAK_HBM_GBS, "ms_per_step": t * 1e3, "bytes_per_launch": nb / n,
+                         "instantiations": sorted(members)}
     dom = max(rows, key=lambda k: rows[k]["ms_per_step"])
     r = rows[dom]
     traffic = None

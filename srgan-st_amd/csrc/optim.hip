@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
 
 }  // namespace
 
-// p, g, m, v: flat fp32 buffers of n floats (n % 4 == 0, 16-byte aligned; pad words are updated harmlessly as long as the
-// caller keeps them finite - flatten_params / flat_grads zero them).  steps: nsteps device floats (all incremented by one,
+// p, g, m, v: flat fp32 buffers of n floats (n % 4 == 0, 16-byte aligned).  Pad words between the parameter slots are updated
+// like any other element and are don't-care: flatten_params zeroes them in p, flat_grads leaves them uninitialised in g, and
+// whatever they hold (NaN included) stays confined to the pad words of p / m / v - no parameter element ever reads one.  steps: nsteps device floats (all incremented by one,
 // steps[0] is the t of this update).  lr: device scalar.
 SST_API int sst_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float* steps, int nsteps,
                           double beta1, double beta2, double eps, double weight_decay, void* stream) {

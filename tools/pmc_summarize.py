@@ -48,6 +48,16 @@ def main():
         if k.startswith("conv_wgrad") and "wgrad_reduce_kernel" in per:
             per[k + "+wgrad_reduce_kernel"] = per[k] + per["wgrad_reduce_kernel"]
             per[k + "(grouped)+wgrad_reduce_kernel"] = per[k] + per["wgrad_reduce_kernel"]
+    # kernel-template families (bench.py: one row for all instantiations of a template), launches-weighted
+    fams = {}
+    for k in raw:
+        fam = re.sub(r"<[^>]*>", "", k)
+        if fam != k:
+            fams.setdefault(fam, []).append(k)
+    for fam, members in fams.items():
+        if len(members) > 1:
+            n = sum(raw[m]["FETCH_SIZE"]["launches"] for m in members)
+            per[fam] = sum(per[m] * raw[m]["FETCH_SIZE"]["launches"] for m in members) / n
     doc["_provenance"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over eager steps of "
                           "bench.py (B=16), tools_pmc_bench.sh + tools/pmc_summarize.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                           "MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of wide coalesced reads; WRITE_SIZE exact); averages over "
