@@ -240,14 +240,16 @@ class TrainEngine:
         # generator's message travels under the first of those graphs.  overlap_comm=False: the round-1 schedule
         # ([fwd+bwd] -> all-reduce -> wait -> [Adam] per network); both give bit-identical parameters (tests/test_dp_gpu.py).
         self.overlap = self.dp and (config.DIST.OVERLAP_COMM if overlap_comm is None else overlap_comm)
-        self._d_a = self._d_b = None
+        self._d_a = self._d_b = self._g_f = self._g_b = None
         self._side = self._side_d = None
         self._it = None
         if self.dp:
             self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self.g_opt.step, enabled=g, on_fail=f)
             self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self._d_step, enabled=g, on_fail=f)
             if self.overlap:
-                self._d_fb = None
+                self._d_fb = self._g_fb = None
+                self._g_f = _GraphedStep(self._g_fwd, enabled=g, on_fail=f)         # generator half split at the end of its forward:
+                self._g_b = _GraphedStep(self._g_bwd, enabled=g, on_fail=f)         # the discriminator branch starts there
                 self._d_a = _GraphedStep(self._d_fwd_cls, enabled=g, on_fail=f)
                 self._d_b = _GraphedStep(self._d_features, enabled=g, on_fail=f)
         else:
@@ -261,7 +263,7 @@ class TrainEngine:
     def _steps(self):
         if self._it is not None:               # merged iterations; generator-only graph between them when D is updated every n-th step
             return [self._it] + ([self._g_fb] if self.config.SOLVER.D_UPDATE_INTERVAL > 1 else [])
-        return [s for s in (self._g_fb, self._g_op, self._d_fb, self._d_a, self._d_b, self._d_op) if s is not None]
+        return [s for s in (self._g_fb, self._g_f, self._g_b, self._g_op, self._d_fb, self._d_a, self._d_b, self._d_op) if s is not None]
 
     def _drop_graphs(self):
         for s in self._steps():
@@ -288,6 +290,24 @@ class TrainEngine:
         self.loss_values = vals
         return vals
 
+    # the same half in two parts (data-parallel schedule: the discriminator branch forks between them)
+    def _g_fwd(self):
+        cfg = self.config
+        for p in self.D.parameters():
+            p.requires_grad = False
+        self.g_opt.zero_grad(set_to_none=True)
+        self.D.__dict__["_packs_fresh"] = False
+        sr = self.G(self.lr)
+        total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
+                                       adversarial=lambda crit: crit(self.D(sr), self.real))
+        self.sr = sr.detach()
+        self.loss_values = vals
+        self._g_total = total
+        return vals
+
+    def _g_bwd(self):
+        self._g_total.backward(_one(self._g_total))
+
     def _g_full(self):
         v = self._g_fwd_bwd()
         self.g_opt.step()
@@ -303,11 +323,22 @@ class TrainEngine:
         pred_sr = self.D(self.sr)                            # train.py:158 detaches + clones; self.sr is detached and D only reads it
         loss_fake = self.adv(pred_sr, self.fake)
         d_loss = loss_real + loss_fake
-        self.D.__dict__["_grad_accum"] = {"flat": None}      # both backward passes write ONE flat gradient buffer (disc_graph.backward)
+        scope = {"flat": None}
+        self.D.__dict__["_grad_accum"] = scope               # both backward passes write ONE flat gradient buffer (disc_graph.backward)
         try:
             d_loss.backward(_one(d_loss))
         finally:
             self.D.__dict__.pop("_grad_accum", None)
+        # The scope relies on autograd ADOPTING the first pass's views as p.grad (no clone) while the second pass adds into the
+        # same buffer and returns nothing.  If a torch version / a hook ever clones instead, the second pass's half of the
+        # gradient would be lost silently: check the aliasing once per (eager or capturing) call.
+        flat = scope["flat"]
+        if flat is not None:
+            lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+            for n, p in self.D.named_parameters():
+                if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                    raise RuntimeError(f"discriminator gradient of {n} is not a view of the accumulation buffer: "
+                                       "the second backward pass would be dropped (engine._d_fwd_bwd)")
         self.d_loss, self.pred_gt, self.pred_sr = d_loss.detach(), pred_gt.detach(), pred_sr.detach()
         return self.d_loss
 
@@ -449,25 +480,37 @@ class TrainEngine:
 
     def close(self):
         """See WarmupEngine.close."""
-        self._g_fb = self._g_op = self._d_fb = self._d_op = self._d_a = self._d_b = self._it = None
+        self._g_fb = self._g_op = self._d_fb = self._d_op = self._d_a = self._d_b = self._it = self._g_f = self._g_b = None
+        self._g_total = None
         self._d_state = self._d_flat = self._d_buckets = None
         self.gt = self.lr = self.sr = None
 
     def _step_overlapped(self):
-        """Data-parallel iteration with the collectives hidden behind compute (see __init__)."""
-        self._g_fb()
-        ar_g = sdist.AsyncAllReduce(sdist.module_flat_grad(self.G), self.pg, force=True)      # travels under the D forward
+        """Data-parallel iteration: collectives hidden behind compute AND the discriminator half beside the generator's backward
+        (the two-branch schedule of _iter_gd with the graphs cut where a collective has to go out):
+            main: [G forward] -------------- [G backward] -> all-reduce(G) ................. -> [G Adam] -> join -> [D Adam]
+            side:        \\-> [D fwd x2 + classifier bwd] -> all-reduce(classifier) || [D feature bwd] -> all-reduce(features)"""
+        main = torch.cuda.current_stream()
         did_d = self.batch_num % self.config.SOLVER.D_UPDATE_INTERVAL == 0
+        self._g_f()
         if did_d:
-            self._d_a()
-            ar_c = sdist.AsyncAllReduce(self._d_buckets[0], self.pg, force=True)              # classifier: 75.5 MB, under the feature backward
-            self._d_b()
-            ar_f = sdist.AsyncAllReduce(self._d_buckets[1], self.pg, force=True)
+            if self._side_d is None:
+                self._side_d = torch.cuda.Stream()
+            side = self._side_d
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._d_a()
+                ar_c = sdist.AsyncAllReduce(self._d_buckets[0], self.pg, force=True)          # classifier: 75.5 MB, under the feature backward
+                self._d_b()
+                ar_f = sdist.AsyncAllReduce(self._d_buckets[1], self.pg, force=True)
+        self._g_b()
+        ar_g = sdist.AsyncAllReduce(sdist.module_flat_grad(self.G), self.pg, force=True)
         if ar_g.flat is None:                                    # gradients not in one flat buffer: the generic path
             sdist.allreduce_module_grads(self.G, self.pg, force=True)
         ar_g.wait()
         self._g_op()
         if did_d:
+            main.wait_stream(side)
             ar_c.wait()
             ar_f.wait()
             self._d_op()
