@@ -333,6 +333,23 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
   const float slope = slope_p ? slope_p[0] : slope_c;
   const int64_t stride = (int64_t)gridDim.x * NT;
   constexpr int U = 4;               // items in flight per thread (loads of a batch issued before the first is used)
+  // The grid stride is a multiple of the channel-quad count for every layer of the path (power-of-two channels): a thread then
+  // keeps ONE channel quad, and its five coefficient quads (scale, shift, cA, cB, cC) are loaded once instead of 20 scalar
+  // loads per item - the kernel was bound by issuing those, not by its 48 B of streaming traffic per item.
+  const bool fixed_c = stride % c4n == 0;
+  f32x4 hsc = {1.f, 1.f, 1.f, 1.f}, hsh = {0.f, 0.f, 0.f, 0.f}, hA = {1.f, 1.f, 1.f, 1.f}, hB = {0.f, 0.f, 0.f, 0.f}, hC = {0.f, 0.f, 0.f, 0.f};
+  if (fixed_c) {
+    const int c = (int)((blockIdx.x * (int64_t)NT + threadIdx.x) % c4n) * 4;
+    if (scale) {
+      hsc = *reinterpret_cast<const f32x4*>(scale + c);
+      hsh = *reinterpret_cast<const f32x4*>(shift + c);
+    }
+    if (cA) {
+      hA = *reinterpret_cast<const f32x4*>(cA + c);
+      hB = *reinterpret_cast<const f32x4*>(cB + c);
+      hC = *reinterpret_cast<const f32x4*>(cC + c);
+    }
+  }
   for (int64_t i0 = blockIdx.x * (int64_t)NT + threadIdx.x; i0 < total; i0 += stride * U) {
     f32x4 gvs[U], yvs[U];
 #pragma unroll
@@ -351,14 +368,26 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
     const f32x4 gv = gvs[u];
     const f32x4 yv = yvs[u];
     f32x4 o;
+    f32x4 ksc = hsc, ksh = hsh, kA = hA, kB = hB, kC = hC;
+    if (!fixed_c) {
+      if (scale) {
+        ksc = *reinterpret_cast<const f32x4*>(scale + c);
+        ksh = *reinterpret_cast<const f32x4*>(shift + c);
+      }
+      if (cA) {
+        kA = *reinterpret_cast<const f32x4*>(cA + c);
+        kB = *reinterpret_cast<const f32x4*>(cB + c);
+        kC = *reinterpret_cast<const f32x4*>(cC + c);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float gz = gv[j];
       if (act) {
-        const float z = scale ? fmaf(yv[j], scale[c + j], shift[c + j]) : yv[j];
+        const float z = scale ? fmaf(yv[j], ksc[j], ksh[j]) : yv[j];
         gz = z > 0.f ? gz : gz * slope;
       }
-      o[j] = cA ? fmaf(cA[c + j], gz, fmaf(cB[c + j], yv[j], cC[c + j])) : gz;
+      o[j] = cA ? fmaf(kA[j], gz, fmaf(kB[j], yv[j], kC[j])) : gz;
     }
     if (uW == 0) {
       reinterpret_cast<f32x4*>(dy)[i] = o;
