@@ -89,6 +89,14 @@ int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const float* bi
                       float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
                       const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
                       int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
+/* stride-2 data-gradient (sst_conv_s2_dgrad below) on the pipelined kernel: the four parity classes of a block of class pixels in
+ * one unit (they share the dY patch), the 9 (class, tap) pairs in the place of the 9 taps, one accumulator per class.  Even H, W;
+ * Cout % 64 == 0, Cin % 32 == 0.  wp = the buffer of sst_conv_s2_dgrad_pack; ws = sst_conv_s2_dgrad_pipe_ws_floats floats (0: none).
+ * sst_conv_s2_dgrad_pipe_supported: tile width when the shape is taken, else 0. */
+int sst_conv_s2_dgrad_pipe_supported(int B, int H, int W, int Cin, int Cout);
+int64_t sst_conv_s2_dgrad_pipe_ws_floats(int B, int H, int W, int Cin, int Cout);
+int sst_conv_s2_dgrad_pipe(const float* dy, const float* wp, float* dx, float* ws, int B, int H, int W, int Cin, int Cout,
+                           void* stream);
 /* stride-1 data-gradient (mode 1 weights) whose epilogue also emits the BatchNorm/activation BACKWARD partial sums of
  * its result g against the saved conv output epi_y: epi_partial [sst_conv_stat_tiles][3][Cout] = per-tile sums of
  * (gz, gz*epi_y, g*min(z,0)) - the layout sst_bwd_finalize consumes (replaces a separate sst_bwd_reduce pass). */

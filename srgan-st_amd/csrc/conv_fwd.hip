@@ -576,6 +576,34 @@ __host__ __device__ inline int64_t s2_class_offset(int cls, int Cin, int Cout) {
   return off;
 }
 __global__ void pack_s2_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+  if (blockIdx.y == 4) {
+    // 5th section, for the pipelined kernel (conv_pipe.hip, stride-2 data-gradient mode): the 9 (class, tap) pairs as the 9
+    // "taps" of ONE forward-layout block list [Cin/32][Cout/64][9][8][256] - pair c = class {0,1,1,2,2,3,3,3,3}[c], tap
+    // {0,0,1,0,1,0,1,2,3}[c] of that class
+    const int O = Cin, I = Cout, ncb = (I + 63) / 64;
+    float* dst = wp + s2_class_offset(4, Cin, Cout);
+    const int64_t total = packed_floats_base(O, I, 9);
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+      const int j = idx & 3, l = (idx >> 2) & 63, ks = (idx >> 8) & 7;
+      int64_t rest = idx >> 11;
+      const int combo = rest % 9;
+      rest /= 9;
+      const int cbk = rest % ncb;
+      const int of = rest / ncb;
+      const int o = of * 32 + (l & 31), i = cbk * 64 + ks * 8 + (l >> 5) * 4 + j;
+      float v = 0.f;
+      if (of < (O + 31) / 32 && o < O && i < I) {
+        const int cls = combo == 0 ? 0 : (combo < 3 ? 1 : (combo < 5 ? 2 : 3));
+        const int tap = combo == 0 ? 0 : (combo < 3 ? combo - 1 : (combo < 5 ? combo - 3 : combo - 5));
+        const int py = cls >> 1, px = cls & 1, ntx = 1 + px;
+        const int jy = tap / ntx, jx = tap - jy * ntx;
+        const int ky = py ? (jy ? 0 : 2) : 1, kx = px ? (jx ? 0 : 2) : 1;
+        v = w[(((size_t)i * Cin + o) * 3 + ky) * 3 + kx];
+      }
+      dst[idx] = v;
+    }
+    return;
+  }
   const int cls = blockIdx.y, py = cls >> 1, px = cls & 1;
   const int nty = 1 + py, ntx = 1 + px, KKc = nty * ntx;
   const int O = Cin, I = Cout, ncb = (I + 63) / 64;
@@ -830,11 +858,13 @@ SST_API int sst_conv_dgrad_fused_acc(const float* g, const float* y2, const floa
 }
 
 // ---- data-gradient of a 3x3 stride-2 pad-1 convolution (Discriminator.features, model.py:35,42,49,56)
-SST_API int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin) { return s2_class_offset(4, Cin, Cout); }
+// 4 per-class sections + the unified 9-pair section of the pipelined kernel
+SST_API int64_t sst_conv_s2_dgrad_packed_floats(int Cout, int Cin) { return s2_class_offset(4, Cin, Cout) + packed_floats_base(Cin, Cout, 9); }
+int64_t sst_conv_s2_dgrad_pipe_section(int Cout, int Cin) { return s2_class_offset(4, Cin, Cout); }     // for conv_pipe.hip
 
 SST_API int sst_conv_s2_dgrad_pack(const float* w, float* wp, int Cout, int Cin, void* stream) {
   SST_REQUIRE(w && wp && Cout > 0 && Cin > 0, "sst_conv_s2_dgrad_pack: bad argument");
-  pack_s2_dgrad_kernel<<<dim3(256, 4), 256, 0, sst_stream(stream)>>>(w, wp, Cout, Cin);
+  pack_s2_dgrad_kernel<<<dim3(256, 5), 256, 0, sst_stream(stream)>>>(w, wp, Cout, Cin);
   SST_LAUNCH_CHECK("pack_s2_dgrad_kernel");
   return SST_OK;
 }

@@ -50,18 +50,26 @@ struct PipeArgs {
   int dbg;
 };
 
-template <int S, int TW>
+// MODE 0: 3x3 conv (pad 1).  MODE 1: data-gradient of a 3x3 / stride-2 / pad-1 conv - the four parity classes of an 8x4 (TW x 32/TW)
+// block of class pixels in one unit: they read the same (TW+1) x (TH+1) patch of dY (no left / top padding, the zero row of the
+// virtual tall image sits BEHIND each image), the 9 (class, tap) pairs take the place of the 9 taps, one accumulator per class.
+template <int S, int TW, int MODE>
 struct PipeGeom {
   static constexpr int TH = 32 / TW;
   static constexpr int NB = TW == 2 ? 3 : 1;                 // image boundaries a tile may cross (host checks Ho against it)
-  static constexpr int PW = (TW - 1) * S + 3;
-  static constexpr int PR = (TH - 1) * S + 3 + NB;
+  static constexpr int KSPAN = MODE ? 2 : 3;
+  static constexpr int PW = (TW - 1) * S + KSPAN;
+  static constexpr int PR = (TH - 1) * S + KSPAN + NB;
   static constexpr int NP = PW * PR;
   static constexpr int NU = (NP + 15) / 16;                  // patch pixels per lane (4 lanes x 16 B = one pixel's 16-channel slice)
   static constexpr int PS = 20;                              // floats per pixel in a wave's patch (16 channels + 4 pad: 16-B aligned rows)
   static constexpr int WAVE_FLOATS = NP * PS;                // one wave's private patch
-  static constexpr int SCRATCH = 4 * 32 * 33;                // K-partial exchange at the end of a unit
+  static constexpr int NACC = MODE ? 4 : 1;                  // accumulators (parity classes)
+  static constexpr int NPAIR = MODE ? 2 : 1;                 // accumulators exchanged per round at the end of a unit
+  static constexpr int SCRATCH = NPAIR * 4 * 32 * 33;        // K-partial exchange at the end of a unit
 };
+constexpr int S2D_CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};     // (class, tap) pair -> class / tap of the class (taps row-major, 1 + (cls & 1) wide)
+constexpr int S2D_TAP[9] = {0, 0, 1, 0, 1, 0, 1, 2, 3};
 
 // one stage = one 64-channel block of one tile's input patch (+ the matching weight block)
 struct Stage {
@@ -95,12 +103,18 @@ __device__ __forceinline__ float half_sum(float t) {
 
 // Epilogue of one 32 px x 32 ch tile, wave-local: this lane holds v[j] = conv result of pixel px = lane & 31 of the tile,
 // channels c0 .. c0+3 (c0 = nf*32 + 8*wave + 4*(lane >> 5)).  No barriers, no LDS.
-template <int TW>
-__device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float v[4], int r0, int ox0, int c0, int mt, int lane, bool first) {
+template <int TW, int MODE = 0>
+__device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float v[4], int r0, int ox0, int c0, int mt, int lane, bool first,
+                                              int cls = 0) {
   constexpr int TH = 32 / TW;
   const int px = lane & 31;
   const int r = r0 + px / TW, ox = ox0 + px % TW;
   const bool pix_ok = r < a.R && ox < a.Wo;
+  if (MODE) {        // stride-2 data-gradient: class (sy, sx) pixel (r, ox) of the tall class grid -> dX pixel (2r + sy, 2ox + sx)
+    const size_t o = ((size_t)(2 * r + (cls >> 1)) * (2 * a.Wo) + 2 * ox + (cls & 1)) * a.Cout + c0;
+    if (pix_ok) *reinterpret_cast<f32x4*>(a.y + o) = f32x4{v[0], v[1], v[2], v[3]};
+    return;
+  }
   if (a.bias) {
     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c0);
 #pragma unroll
@@ -157,9 +171,10 @@ __device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float v[4], int
   }
 }
 
-template <int S, int TW>
-__global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(PipeArgs a) {
-  using G = PipeGeom<S, TW>;
+template <int S, int TW, int MODE>
+__global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_pipe_kernel(PipeArgs a) {
+  using G = PipeGeom<S, TW, MODE>;
+  constexpr int NACC = G::NACC, NPAIR = G::NPAIR;
   constexpr int PW = G::PW, NP = G::NP, NU = G::NU, NB = G::NB;
   constexpr int PS = G::PS;
   __shared__ __attribute__((aligned(16))) float patch[4 * G::WAVE_FLOATS];   // [wave][patch pixel][16 channels + pad]
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
     Stage s;
     s.b0 = b0_;
     s.rem0 = oy0_ * S;
-    s.ix0 = ox0_ * S - 1;
+    s.ix0 = ox0_ * S - (MODE ? 0 : 1);
     s.c0 = cb_ * CB;
     s.w = a.wp + ((size_t)(nf_ * a.ncb + cb_) * 9 * 8) * 256 + wave * 512;
     return s;
@@ -224,8 +239,8 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
         rr -= wrap ? HV : 0;
         b += wrap ? 1 : 0;
       }
-      const int iy = rr - 1, ix = s.ix0 + pc;
-      const bool ok = p < NP && rr >= 1 && b < a.B && (unsigned)ix < (unsigned)a.W;
+      const int iy = MODE ? rr : rr - 1, ix = s.ix0 + pc;        // MODE 0: virtual row 0 of an image is its (shared) zero row; MODE 1: row H is
+      const bool ok = p < NP && (MODE ? rr < a.H : rr >= 1) && b < a.B && (unsigned)ix < (unsigned)a.W;
       const int off = ((b * a.H + iy) * a.W + ix) * a.Cin + s.c0 + c4;          // < 2^29 floats (host check)
       const unsigned boff = (ok ? (unsigned)off : (unsigned)c4) * 4u;
       PIPE_GLOAD(sv[u], boff, a.x);
@@ -278,9 +293,11 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
   __builtin_amdgcn_sched_barrier(0);
   stage_store();
 
-  f32x16 acc;
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k = 0; k < NACC; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
   for (;;) {
     // ---- what comes after the current stage (wave-uniform)
@@ -319,13 +336,17 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
       for (int i = 0; i < 18; ++i) {
         f32x4 an = av;
         if (i + 1 < 18) {
-          const int t = (i + 1) >> 1;
-          an = *reinterpret_cast<const f32x4*>(ab + ((t / 3) * PW + (t % 3)) * PS + ((i + 1) & 1) * 8);
+          const int t = (i + 1) >> 1;                  // tap (MODE 0) / (class, tap) pair (MODE 1) of the next chunk
+          const int ntx = MODE ? 1 + (S2D_CLS[t] & 1) : 3, tt = MODE ? S2D_TAP[t] : t;
+          an = *reinterpret_cast<const f32x4*>(ab + ((tt / ntx) * PW + (tt % ntx)) * PS + ((i + 1) & 1) * 8);
         }
         if (i == 0 || i >= 10) PIPE_WAIT(ring[i % PIPE_RING], 8); else PIPE_WAIT(ring[i % PIPE_RING], 8 + NS);
         const f32x4 bv = ring[i % PIPE_RING];
+        constexpr int dummy_ = 0;
+        (void)dummy_;
+        const int ai = MODE ? S2D_CLS[i >> 1] : 0;     // compile-time after unrolling
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[ai], 0, 0, 0);
         if (i + PIPE_RING < 18) PIPE_WCHUNK(ring[i % PIPE_RING], cur.w, i + PIPE_RING);
         else PIPE_WCHUNK(ring[i % PIPE_RING], nxt.w, i + PIPE_RING - 18);
         if (i == 0) stage_load(nxt);
@@ -334,35 +355,45 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
       }
     }
     if (unit_end && (a.dbg & 2)) {
-      if (acc[0] == 12345.f) a.y[0] = acc[0];
+      if (acc[0][0] == 12345.f) a.y[0] = acc[0][0];
       if (!more) return;
       a_base = lane_base(n_oy0);
     } else if (unit_end) {
-      // ---- the 4 waves' K-partials -> LDS; afterwards wave w owns channels 8w .. 8w+7 of the tile for all 32 pixels
-      __syncthreads();                     // everyone has read the previous unit's partials
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        scratch[(wave * 32 + row) * 33 + li] = acc[r];
-        acc[r] = 0.f;
-      }
-      __syncthreads();
+      // ---- the 4 waves' K-partials -> LDS (NPAIR accumulators per round); afterwards wave w owns channels 8w .. 8w+7 of the
+      // tile for all 32 pixels
       const int cl = 8 * wave + 4 * lh;    // first of this lane's 4 channels inside the 32-channel block
-      float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = scratch[(0 * 32 + li) * 33 + cl + j];
-        t += scratch[(1 * 32 + li) * 33 + cl + j];
-        t += scratch[(2 * 32 + li) * 33 + cl + j];
-        t += scratch[(3 * 32 + li) * 33 + cl + j];
-        v[j] = t;
-      }
-      if (a.ksplit > 1) {
-        const int tile = nf * a.n_mt + mt;
-        const int part = cb / a.cb_per;
-        *reinterpret_cast<f32x4*>(a.ws + ((size_t)part * a.total_tiles + tile) * 1024 + li * 32 + cl) = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
-        pipe_epilogue<TW>(a, v, r0, ox0, nf * 32 + cl, mt, lane, nf == 0 && wave == 0);
+      for (int k0 = 0; k0 < NACC; k0 += NPAIR) {
+        __syncthreads();                   // everyone has read the previous round's partials
+#pragma unroll
+        for (int k = 0; k < NPAIR; ++k)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            scratch[((k * 4 + wave) * 32 + row) * 33 + li] = acc[k0 + k][r];
+            acc[k0 + k][r] = 0.f;
+          }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPAIR; ++k) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = scratch[((k * 4 + 0) * 32 + li) * 33 + cl + j];
+            t += scratch[((k * 4 + 1) * 32 + li) * 33 + cl + j];
+            t += scratch[((k * 4 + 2) * 32 + li) * 33 + cl + j];
+            t += scratch[((k * 4 + 3) * 32 + li) * 33 + cl + j];
+            v[j] = t;
+          }
+          if (a.ksplit > 1) {
+            const int tile = nf * a.n_mt + mt;
+            const int part = cb / a.cb_per;
+            *reinterpret_cast<f32x4*>(a.ws + (((size_t)part * a.total_tiles + tile) * NACC + k0 + k) * 1024 + li * 32 + cl) =
+                f32x4{v[0], v[1], v[2], v[3]};
+          } else {
+            pipe_epilogue<TW, MODE>(a, v, r0, ox0, nf * 32 + cl, mt, lane, nf == 0 && wave == 0, k0 + k);
+          }
+        }
       }
       if (!more) return;
       a_base = lane_base(n_oy0);
@@ -374,22 +405,25 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 ? 3 : 2)) void conv_pipe_kernel(Pi
   }
 }
 
-// Split-K: sum the partial slabs of one tile in fixed order, then the ordinary (wave-local) epilogue.
-template <int TW>
+// Split-K: sum the partial slabs of one tile (and parity class) in fixed order, then the ordinary (wave-local) epilogue.
+template <int TW, int MODE>
 __global__ __launch_bounds__(CONV_NT) void pipe_reduce_kernel(PipeArgs a) {
+  constexpr int NACC = MODE ? 4 : 1;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int tile = blockIdx.x;
+  const int tile = blockIdx.x / NACC, cls = blockIdx.x - tile * NACC;
   const int nf = tile / a.n_mt, mt = tile - nf * a.n_mt;
   const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
   const int li = lane & 31, cl = 8 * wave + 4 * (lane >> 5);
-  f32x4 s = *reinterpret_cast<const f32x4*>(a.ws + (size_t)tile * 1024 + li * 32 + cl);
+  const size_t slab = (size_t)a.total_tiles * NACC * 1024;
+  const float* src = a.ws + ((size_t)tile * NACC + cls) * 1024 + li * 32 + cl;
+  f32x4 s = *reinterpret_cast<const f32x4*>(src);
   for (int k = 1; k < a.ksplit; ++k) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(a.ws + ((size_t)k * a.total_tiles + tile) * 1024 + li * 32 + cl);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(src + k * slab);
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] += t[j];
   }
   float v[4] = {s[0], s[1], s[2], s[3]};
-  pipe_epilogue<TW>(a, v, ty * (32 / TW), tx * TW, nf * 32 + cl, mt, lane, nf == 0 && wave == 0);
+  pipe_epilogue<TW, MODE>(a, v, ty * (32 / TW), tx * TW, nf * 32 + cl, mt, lane, nf == 0 && wave == 0, cls);
 }
 
 struct PipePlan {
@@ -474,10 +508,10 @@ SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const f
   hipStream_t st = sst_stream(stream);
 #define SST_PIPE_LAUNCH(S_, TW_)                                                                  \
   do {                                                                                            \
-    conv_pipe_kernel<S_, TW_><<<grid, CONV_NT, 0, st>>>(a);                                       \
+    conv_pipe_kernel<S_, TW_, 0><<<grid, CONV_NT, 0, st>>>(a);                                    \
     SST_LAUNCH_CHECK("conv_pipe_kernel");                                                         \
     if (pl.ksplit > 1) {                                                                          \
-      pipe_reduce_kernel<TW_><<<a.total_tiles, CONV_NT, 0, st>>>(a);                              \
+      pipe_reduce_kernel<TW_, 0><<<a.total_tiles, CONV_NT, 0, st>>>(a);                           \
       SST_LAUNCH_CHECK("pipe_reduce_kernel");                                                     \
     }                                                                                             \
   } while (0)
@@ -487,5 +521,77 @@ SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const f
     if (pl.tw == 8) SST_PIPE_LAUNCH(2, 8); else if (pl.tw == 4) SST_PIPE_LAUNCH(2, 4); else SST_PIPE_LAUNCH(2, 2);
   }
 #undef SST_PIPE_LAUNCH
+  return SST_OK;
+}
+
+// ---- stride-2 data-gradient on the pipelined kernel (MODE 1).  dx [B,H,W,Cin] = conv_transpose(dy [B,H/2,W/2,Cout]) for
+// y = conv3x3(x, stride 2, pad 1); wp = the buffer of sst_conv_s2_dgrad_pack (its 5th section).  Even H, W; Cout % 64 == 0
+// (K blocks), Cin % 32 == 0.
+int64_t sst_conv_s2_dgrad_pipe_section(int Cout, int Cin);      // conv_fwd.hip
+
+namespace {
+PipePlan pipe_plan_s2d(int B, int H, int W, int Cin, int Cout) {
+  PipePlan pl{};
+  if (B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || (Cout % 64) || (Cin % 32)) return pl;
+  const int Hd = H / 2, Wd = W / 2;                  // class grid = dY size
+  int tw = 0;
+  if (Wd % 8 == 0 && Hd >= 3) tw = 8;
+  else if (Wd % 4 == 0 && Hd >= 7) tw = 4;
+  else if (Wd % 2 == 0 && Hd >= 5) tw = 2;
+  if (!tw) return pl;
+  const int th = 32 / tw;
+  pl.tiles_x = Wd / tw;
+  pl.n_mt = pl.tiles_x * ((B * Hd + th - 1) / th);
+  pl.nfc = Cin / 32;
+  pl.ncb = Cout / 64;
+  const long tiles = (long)pl.n_mt * pl.nfc;
+  int maxks = 1;
+  while (maxks < 4 && pl.ncb % (maxks * 2) == 0) maxks *= 2;
+  if (tiles * maxks < 256) return pl;
+  int ks = 1;
+  while (tiles * ks < 1024 && ks < maxks) ks *= 2;
+  // measured against conv_s2dgrad4_kernel (tools/time_s2d.py, B = 16): 96 px 38.7 vs 39.7 us, 48 px 34.0 vs 35.4, 12 px 38.2 vs 46.9
+  // (its 8x4 tiles waste 44 % of the MFMAs on a 6x6 class grid), but 24 px 40.2 vs 37.6: four epilogues per unit + a split-K
+  // reduce launch cost more than the 25 % tile waste they remove - that middle case stays on the merged-classes kernel
+  if (tw == 4 && ks > 1) return pl;
+  pl.ksplit = ks;
+  pl.tw = tw;
+  return pl;
+}
+}  // namespace
+
+SST_API int sst_conv_s2_dgrad_pipe_supported(int B, int H, int W, int Cin, int Cout) { return pipe_plan_s2d(B, H, W, Cin, Cout).tw; }
+SST_API int64_t sst_conv_s2_dgrad_pipe_ws_floats(int B, int H, int W, int Cin, int Cout) {
+  const PipePlan pl = pipe_plan_s2d(B, H, W, Cin, Cout);
+  return (pl.tw && pl.ksplit > 1) ? (int64_t)pl.ksplit * pl.n_mt * pl.nfc * 4 * 1024 : 0;
+}
+SST_API int sst_conv_s2_dgrad_pipe(const float* dy, const float* wp, float* dx, float* ws, int B, int H, int W, int Cin, int Cout,
+                                   void* stream) {
+  SST_REQUIRE(dy && wp && dx, "sst_conv_s2_dgrad_pipe: null pointer");
+  const PipePlan pl = pipe_plan_s2d(B, H, W, Cin, Cout);
+  SST_REQUIRE(pl.tw, "sst_conv_s2_dgrad_pipe: shape B=%d H=%d W=%d Cin=%d Cout=%d is not taken by the pipelined kernel", B, H, W, Cin, Cout);
+  SST_REQUIRE(pl.ksplit == 1 || ws, "sst_conv_s2_dgrad_pipe: this shape splits K over workgroups and needs the workspace");
+  SST_REQUIRE((int64_t)B * (H / 2) * (W / 2) * Cout < (1ll << 29), "sst_conv_s2_dgrad_pipe: input too large for 32-bit byte offsets");
+  PipeArgs a{};
+  a.x = dy; a.wp = wp + sst_conv_s2_dgrad_pipe_section(Cout, Cin); a.y = dx; a.ws = ws;
+  a.in_act = ACT_NONE;
+  a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.Cout = Cin;      // GEMM view: K = dY channels, N = dX channels
+  a.Ho = a.H; a.Wo = a.W; a.R = B * a.Ho;
+  a.tiles_x = pl.tiles_x; a.n_mt = pl.n_mt; a.nfc = pl.nfc; a.total_tiles = pl.n_mt * pl.nfc; a.ncb = pl.ncb;
+  a.ksplit = pl.ksplit; a.cb_per = pl.ncb / pl.ksplit; a.units = a.total_tiles * pl.ksplit;
+  a.dbg = 0;
+  const int grid = a.units < 2 * PIPE_CUS ? a.units : 2 * PIPE_CUS;
+  hipStream_t st = sst_stream(stream);
+#define SST_S2D_LAUNCH(TW_)                                                                       \
+  do {                                                                                            \
+    conv_pipe_kernel<1, TW_, 1><<<grid, CONV_NT, 0, st>>>(a);                                     \
+    SST_LAUNCH_CHECK("conv_pipe_kernel (stride-2 data-gradient)");                                \
+    if (pl.ksplit > 1) {                                                                          \
+      pipe_reduce_kernel<TW_, 1><<<a.total_tiles * 4, CONV_NT, 0, st>>>(a);                       \
+      SST_LAUNCH_CHECK("pipe_reduce_kernel (stride-2 data-gradient)");                            \
+    }                                                                                             \
+  } while (0)
+  if (pl.tw == 8) SST_S2D_LAUNCH(8); else if (pl.tw == 4) SST_S2D_LAUNCH(4); else SST_S2D_LAUNCH(2);
+#undef SST_S2D_LAUNCH
   return SST_OK;
 }

@@ -153,7 +153,7 @@ def _conv_pipe(x, wp, y, cout, ksize, stride, bias=None, in_scale=None, in_shift
     check(L.sst_conv_pipe_fwd(*args, stream_ptr()), "sst_conv_pipe_fwd")
     ho, wo = conv_out_hw(H, W, ksize, stride)
     flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
-    name = f"conv_pipe_kernel<{stride}, {L.sst_conv_pipe_supported(*shp)}>" if (PROFILE is not None or TRACE is not None) else ""
+    name = f"conv_pipe_kernel<{stride}, {L.sst_conv_pipe_supported(*shp)}, 0>" if (PROFILE is not None or TRACE is not None) else ""
     _prof_end(e0, name, flops)
     _trace(name, flops, lambda: L.sst_conv_pipe_fwd(*args, stream_ptr()),
            x, wp, y, bias, in_scale, in_shift, in_slope, stats, cnt, partial, ws, *[v for v in e.values() if torch.is_tensor(v)])
@@ -453,6 +453,18 @@ def conv_s2_dgrad(dy, wp, H, W, cin):
     """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] for y = conv3x3(x, stride 2, pad 1)."""
     B, ho, wo, cout = dy.shape
     dx = _f32(B, H, W, cin, like=dy)
+    L = _abi.lib()
+    if os.environ.get("SST_CONV_PIPE", "1") != "0" and L.sst_conv_s2_dgrad_pipe_supported(B, H, W, cin, cout):
+        nws = L.sst_conv_s2_dgrad_pipe_ws_floats(B, H, W, cin, cout)
+        ws = _f32(nws, like=dy) if nws else None
+        args = (ptr(dy), ptr(wp), ptr(dx), ptr(ws), B, H, W, cin, cout)
+        e0 = _prof_begin()
+        check(L.sst_conv_s2_dgrad_pipe(*args, stream_ptr()), "sst_conv_s2_dgrad_pipe")
+        if PROFILE is not None or TRACE is not None:
+            name, flops = f"conv_pipe_kernel<1, {L.sst_conv_s2_dgrad_pipe_supported(B, H, W, cin, cout)}, 1>", 2.0 * B * ho * wo * cout * cin * 9
+            _prof_end(e0, name, flops)
+            _trace(name, flops, lambda: L.sst_conv_s2_dgrad_pipe(*args, stream_ptr()), dy, wp, dx, ws)
+        return dx
     e0 = _prof_begin()
     check(_abi.lib().sst_conv_s2_dgrad(ptr(dy), ptr(wp), ptr(dx), B, H, W, cin, cout, stream_ptr()), "sst_conv_s2_dgrad")
     if PROFILE is not None or TRACE is not None:

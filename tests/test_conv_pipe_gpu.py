@@ -125,3 +125,44 @@ def test_conv_pipe_equals_general_kernel(ops, monkeypatch):
     y0, _, st0, _ = ops.conv_fwd(x, wp, Cout, 3, s, want_stats=True)
     assert st0.shape[0] != st1.shape[0]                       # different statistics tilings: 96 (8x4, padded) vs 72 (tall image)
     assert rel_err(y1.cpu(), y0.cpu()) < 1e-5
+
+
+# stride-2 data-gradient mode: (B, H, W, Cin, Cout) of the conv whose input gradient is computed -> (tile width, K-split)
+S2D_CASES = {
+    (16, 96, 96, 64, 64): (8, 1),          # discriminator layer 2
+    (16, 48, 48, 128, 128): (8, 1),        # layer 4
+    (16, 24, 24, 256, 256): (0, 0),        # layer 6 (12 x 12 class grid, would split K): measured slower, stays on conv_s2dgrad4_kernel
+    (16, 24, 24, 128, 64): (4, 1),         # 12 x 12 class grid, 8-row tiles straddle images
+    (16, 12, 12, 512, 512): (2, 4),        # layer 8: 6 x 6 class grid, 16-row tiles, K split 4 ways
+    (5, 44, 48, 128, 64): (8, 1),          # class grid 22 x 24: straddling tiles, partial last tile
+    (6, 28, 24, 256, 64): (4, 1),
+    (9, 20, 12, 512, 64): (2, 1),
+}
+
+
+@pytest.mark.parametrize("case", list(S2D_CASES))
+def test_conv_pipe_stride2_dgrad(ops, case, monkeypatch):
+    """Data-gradient of a 3x3 / stride-2 / pad-1 conv on the pipelined kernel (four parity classes per unit) vs torch fp64, and
+    against the merged-classes kernel it replaces (SST_CONV_PIPE=0)."""
+    from srganst import _abi
+    B, H, W, Cin, Cout = case
+    tw, ks = S2D_CASES[case]
+    L = _abi.lib()
+    assert L.sst_conv_s2_dgrad_pipe_supported(B, H, W, Cin, Cout) == tw
+    if tw:
+        n_mt = (W // 2 // tw) * ((B * (H // 2) + 32 // tw - 1) // (32 // tw))
+        assert L.sst_conv_s2_dgrad_pipe_ws_floats(B, H, W, Cin, Cout) == (ks * n_mt * (Cin // 32) * 4 * 1024 if ks > 1 else 0)
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    y = F.conv2d(x, w.double(), None, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    wp = ops.pack_conv_s2_dgrad(w.cuda())
+    dyd = nhwc(dy).cuda()
+    dx = ops.conv_s2_dgrad(dyd, wp, H, W, Cin)
+    assert rel_err(nchw(dx.cpu()), x.grad) < TOL
+    assert torch.equal(dx, ops.conv_s2_dgrad(dyd, wp, H, W, Cin))          # fixed-order reductions: bit-identical relaunch
+    monkeypatch.setenv("SST_CONV_PIPE", "0")
+    dx0 = ops.conv_s2_dgrad(dyd, wp, H, W, Cin)
+    assert rel_err(dx.cpu(), dx0.cpu()) < 1e-5
