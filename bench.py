@@ -318,12 +318,17 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", "--no-full-step", dest="no_secondary", action="store_true",
                     help="skip the secondary SRResNet (configs[1]) measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 code path with several "
+                         "ranks sharing one GPU: ranks then map onto the visible devices modulo their count)")
     args = ap.parse_args()
 
     from srganst import _abi, dist as sdist, ops as _ops
     _abi.lib()                                    # fail loudly if the HIP extension is missing
     _ops.OVERLAP = bool(args.overlap) and not args.no_overlap
-    rank, local, world = sdist.init_from_env("nccl")
+    if args.backend == "gloo":
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    rank, local, world = sdist.init_from_env(args.backend)
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)

@@ -103,6 +103,12 @@ class _GraphedStep:
                 torch.cuda.current_stream().wait_stream(s)
                 return out
             launch_stream = torch.cuda.current_stream()
+            # No cyclic garbage collection while the stream captures: a collection that happens to free an OLD CUDAGraph (a
+            # previous engine of the process) calls hipGraphDestroy inside the open capture - "operation not permitted when stream
+            # is capturing", thrown from the destructor, process terminated (seen in tests that build several engines in a row).
+            import gc
+            gc_was_enabled = gc.isenabled()
+            gc.disable()
             try:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: calls made by OTHER threads during capture (e.g. the RCCL watchdog polling its events)
@@ -126,7 +132,12 @@ class _GraphedStep:
                 self.drop()
                 if self.on_fail is not None:
                     self.on_fail()
+                if gc_was_enabled:
+                    gc.enable()
                 return self.fn()
+            finally:
+                if gc_was_enabled:
+                    gc.enable()
         self.graph.replay()
         return self.out
 

@@ -127,6 +127,7 @@ def _nccl_worker(port, q):
         torch.cuda.synchronize()
         assert eng._fb.graph is not None, "hipGraph capture fell back to eager next to a live RCCL communicator"
         out.append({k: v.cpu().numpy() for k, v in G.state_dict().items()})
+        eng.close()                 # release this engine's graphs now (not by a cyclic collection during a later capture)
     # the full G + D step (train.py:100-164): [G fwd+bwd graph] -> all-reduce -> [G Adam] -> [D fwd+bwd graph] -> 2-bucket all-reduce -> [D Adam]
     from srganst.engine import TrainEngine
     from srganst.model import Discriminator
@@ -149,6 +150,7 @@ def _nccl_worker(port, q):
         sd = {"G." + k: v.cpu().numpy() for k, v in G.state_dict().items()}
         sd.update({"D." + k: v.cpu().numpy() for k, v in D.state_dict().items()})
         out.append(sd)
+        eng.close()
     q.put(out)
     td.barrier()
     td.destroy_process_group()
