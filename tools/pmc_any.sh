@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc_any.sh <tag> <script.py> <counters...>   (one --pmc pass over a dev script under tools/)
+# usage: tools/pmc_any.sh <tag> <script.py> <counters...>   (one --pmc pass over a dev script under tools/)
 tag=$1; shift; script=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmca_$tag
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise one rocprofv3 --pmc pass of SQ counters (tools_pmc_bench.sh sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
+"""Summarise one rocprofv3 --pmc pass of SQ counters (tools/r02_refresh.sh: SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS) per kernel.
 usage: pmc_sq_summary.py <counter_collection.csv> [clock_GHz]
 mfma_busy% = SQ_VALU_MFMA_BUSY_CYCLES per SIMD (1024 SIMDs) / (kernel duration * clock); the other columns are fractions of

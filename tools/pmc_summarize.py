@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools_pmc_bench.sh) into profiles/pmc_traffic.json.
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/r02_refresh.sh) into profiles/pmc_traffic.json.
 
 usage: pmc_summarize.py <workload> <fetch_dir> <write_dir>
 HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: both counters are in KB; on gfx950
@@ -59,7 +59,7 @@ def main():
             n = sum(raw[m]["FETCH_SIZE"]["launches"] for m in members)
             per[fam] = sum(per[m] * raw[m]["FETCH_SIZE"]["launches"] for m in members) / n
     doc["_provenance"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over eager steps of "
-                          "bench.py (B=16), tools_pmc_bench.sh + tools/pmc_summarize.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                          "bench.py (B=16), tools/r02_refresh.sh + tools/pmc_summarize.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                           "MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of wide coalesced reads; WRITE_SIZE exact); averages over "
                           "all launches of a kernel name in the run")
     doc.setdefault("_raw_KB", {})[workload] = raw

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 kernel trace: per (kernel, grid) time per step.  usage: tools_summarize.py <dir> [steps]"""
+"""Summarise a rocprofv3 kernel trace: per (kernel, grid) time per step.  usage: tools/summarize_trace.py <dir> [steps]"""
 import collections, csv, glob, sys
 d = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 25.0
 f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
