@@ -45,14 +45,14 @@ def structure_tensor(im: torch.Tensor, sigma: float = 1.0, rho: float = 10.0) ->
 
     Every conv2d zero-pads its own input ('same'), and conv2d is cross-correlation.
     """
-    g, dg = gaussian_kernel(sigma, also_dg=True, dtype=im.dtype)
+    g, dg = (t.to(im.device) for t in gaussian_kernel(sigma, also_dg=True, dtype=im.dtype))
     h = (1, 1, -1, 1)
     w = (1, 1, 1, -1)
     Ix = F.conv2d(im, dg.reshape(h), padding="same")
     Ix = F.conv2d(Ix, g.reshape(w), padding="same")
     Iy = F.conv2d(im, g.reshape(h), padding="same")
     Iy = F.conv2d(Iy, dg.reshape(w), padding="same")
-    k = gaussian_kernel(rho, dtype=im.dtype)
+    k = gaussian_kernel(rho, dtype=im.dtype).to(im.device)
 
     def integ(p):
         p = F.conv2d(p, k.reshape(h), padding="same")

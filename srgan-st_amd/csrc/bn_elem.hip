@@ -170,13 +170,16 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ shift, const float* __restrict__ slope_p,
                                                         float slope_c, int act, float* __restrict__ partial, int64_t R,
                                                         int C, int rows_per_block) {
-  extern __shared__ float sm[];  // [rowlanes][3][C]
+  // The three sums are signed and largely cancel (the BatchNorm gradients and, summed over channels, the scalar PReLU-slope
+  // gradient): every accumulation is fp64 like the reference's CPU path (acc_type<float> = double), only the block partial is
+  // rounded to fp32 once.  Step time unchanged (5.80 ms before and after, the kernel is bound by its loads).
+  extern __shared__ double smd[];  // [rowlanes][3][C]
   const int c4n = C >> 2;
   const int rowlanes = NT / c4n;
   const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
   const int c = cl * 4;
   const float slope = slope_p ? slope_p[0] : slope_c;
-  f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
   if (scale) {
 #pragma unroll
@@ -194,11 +197,11 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
         const float z = fmaf(yv[j], sc[j], sh[j]);
         float gz = gv[j];
         if (act) {
-          s2[j] += gz * fminf(z, 0.f);
+          s2[j] += (double)(gz * fminf(z, 0.f));
           gz = z > 0.f ? gz : gz * slope;
         }
-        s0[j] += gz;
-        s1[j] += gz * yv[j];
+        s0[j] += (double)gz;
+        s1[j] += (double)(gz * yv[j]);
       }
     };
     int64_t r = r0 + rl;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
       if (g2) gv += reinterpret_cast<const f32x4*>(g2)[r * c4n + cl];
       accumulate(gv, reinterpret_cast<const f32x4*>(y)[r * c4n + cl]);
     }
-    float* d = sm + (size_t)rl * 3 * C;
+    double* d = smd + (size_t)rl * 3 * C;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       d[c + j] = s0[j];
@@ -230,9 +233,9 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * C; i += NT) {
-    float t = 0.f;
-    for (int q = 0; q < rowlanes; ++q) t += sm[(size_t)q * 3 * C + i];
-    partial[(size_t)blockIdx.x * 3 * C + i] = t;
+    double t = 0.0;
+    for (int q = 0; q < rowlanes; ++q) t += smd[(size_t)q * 3 * C + i];
+    partial[(size_t)blockIdx.x * 3 * C + i] = (float)t;
   }
 }
 
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
 constexpr int F2T = 1024;
 __global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f,
                                                             float* __restrict__ scratch, unsigned* __restrict__ counter) {
-  __shared__ float sm[3][F2T];
+  __shared__ double sm[3][F2T];
   __shared__ float red[F2T / 64];
   __shared__ unsigned s_last;
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -253,34 +256,38 @@ __global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restr
   const int cstep = gridDim.x * 64;
   for (int cb = blockIdx.x * 64; cb < C; cb += cstep) {
     const int c = cb + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    // the partials are summed in fp64 and sum gz*(y - mean) = S1 - mean*S0 is evaluated in fp64: it cancels, and what fp32 loses
+    // there comes back as a common-mode error of dy over the whole channel (see conv_band.hip, same arithmetic)
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
     if (c < C) {
 #pragma unroll 12
       for (int b = q; b < nblk; b += F2T / 64) {
         const float* p = partial + (size_t)b * 3 * C + c;
-        s0 += p[0];
-        s1 += p[C];
-        s2 += p[2 * C];
+        d0 += (double)p[0];
+        d1 += (double)p[C];
+        d2 += (double)p[2 * C];
       }
     }
     __syncthreads();
-    sm[0][threadIdx.x] = s0;
-    sm[1][threadIdx.x] = s1;
-    sm[2][threadIdx.x] = s2;
+    sm[0][threadIdx.x] = d0;
+    sm[1][threadIdx.x] = d1;
+    sm[2][threadIdx.x] = d2;
     __syncthreads();
     if (q == 0 && c < C) {
-      s0 = s1 = s2 = 0.f;
+      d0 = d1 = d2 = 0.0;
 #pragma unroll
       for (int i = 0; i < F2T / 64; ++i) {
-        s0 += sm[0][cl + 64 * i];
-        s1 += sm[1][cl + 64 * i];
-        s2 += sm[2][cl + 64 * i];
+        d0 += sm[0][cl + 64 * i];
+        d1 += sm[1][cl + 64 * i];
+        d2 += sm[2][cl + 64 * i];
       }
+      const float s0 = (float)d0, s2 = (float)d2;
       al += s2;
       if (f.mean) {
         const float mu = f.mean[c], rs = f.rstd[c], ga = f.gamma[c];
-        const float sgh = rs * (s1 - mu * s0);
-        const float m1 = s0 / f.n, m2 = sgh / f.n;
+        const double sgh_d = (double)rs * (d1 - (double)mu * d0);
+        const float sgh = (float)sgh_d;
+        const float m1 = (float)(d0 / (double)f.n), m2 = (float)(sgh_d / (double)f.n);
         if (f.accumulate) {
           f.dgamma[c] += sgh;
           f.dbeta[c] += s0;
@@ -475,7 +482,7 @@ static int launch_bwd_reduce(const float* g, const float* g2, const float* y, co
   const int nblk = sst_bwd_reduce_blocks(R, C);
   const int rpb = (int)((R + nblk - 1) / nblk);
   const int rowlanes = NT / (C / 4);
-  const size_t smem = (size_t)rowlanes * 3 * C * sizeof(float);
+  const size_t smem = (size_t)rowlanes * 3 * C * sizeof(double);
   bwd_reduce_kernel<<<nblk, NT, smem, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, rpb);
   SST_LAUNCH_CHECK("bwd_reduce_kernel");
   return SST_OK;

@@ -52,6 +52,25 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// The same in fp64 (signed sums that largely cancel: bias / BatchNorm / slope gradients).
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int NT>
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  v = wave_sum_d(v);
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t += red[i];
+  return t;
+}
+
 // Agent-scope hand-off used by "last block reduces" epilogues (cdna guide, Guideline 16):
 // the single publishing lane stores its partial(s), releases, then takes a ticket.
 __device__ __forceinline__ unsigned publish_and_ticket(unsigned* counter) {

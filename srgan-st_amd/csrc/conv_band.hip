@@ -42,6 +42,7 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
   __shared__ float saff[4][3][16];
   __shared__ float sslope[4];
   __shared__ double ssq[4][16];
+  __shared__ double sbw[4][3][16];
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int W = a.W, PW = W + 2, npatch = (R + 2) * PW;
@@ -163,9 +164,11 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
       float s2f = 0.f;
       if (lane < 16) {
         const int ch = wave * 16 + lane;
-        const float s0 = (float)S0, s1 = (float)S1;
-        const float sgh = rs * (s1 - mu * s0);               // same arithmetic as bwd_finalize2_kernel
-        const float m1 = s0 / ba.bw_n, m2 = sgh / ba.bw_n;
+        // sum gz*(y - mean) = S1 - mean*S0 cancels (both terms grow with |mean|): evaluated in fp64 like the sums themselves - an
+        // error here is a COMMON-MODE error of dy over the whole channel, which later signed sums amplify by sqrt(N)
+        const double sgh_d = (double)rs * (S1 - (double)mu * S0);     // same arithmetic as bwd_finalize2_kernel
+        const float s0 = (float)S0, sgh = (float)sgh_d;
+        const float m1 = (float)(S0 / (double)ba.bw_n), m2 = (float)(sgh_d / (double)ba.bw_n);
         const float aa = ga * rs;
         saff[wave][0][lane] = aa;
         saff[wave][1][lane] = -aa * rs * m2;
@@ -426,9 +429,13 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
   if (epi_sums) {
     // backward partials of the stored g against epi_y (see Conv3Args): sums of (gz, gz*y, g*min(z,0)) over the band
     const float eslope = a.epi_slope ? a.epi_slope[0] : a.epi_slope_const;
-    f32x4 q[3];
+    // fp64 from the first add (terms formed in fp32 like the reference's): the sums are signed and largely cancel, and what a band
+    // loses in fp32 is not given back by the fp64 accumulators behind it
+    double q[3][4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) q[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[k][j] = 0.0;
 #pragma unroll
     for (int i = 0; i < MYB; ++i) {
       if (!have[i]) continue;
@@ -442,28 +449,28 @@ __global__ __launch_bounds__(CONV_NT, (NB == 3 ? 3 : 1)) void conv_band_kernel(C
           q2 = gq * fminf(z, 0.f);
           gz = z > 0.f ? gq : gq * eslope;
         }
-        q[0][j] += gz;
-        q[1][j] = fmaf(gz, yv[j], q[1][j]);
-        q[2][j] += q2;
+        q[0][j] += (double)gz;
+        q[1][j] += (double)(gz * yv[j]);
+        q[2][j] += (double)q2;
       }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q[k][j] = reduce16(q[k][j]);
+      for (int j = 0; j < 4; ++j) q[k][j] = reduce16_d(q[k][j]);
     __syncthreads();
     if (lp16 == 0) {
 #pragma unroll
       for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sstat[wave][k][4 * lj + j] = q[k][j];
+        for (int j = 0; j < 4; ++j) sbw[wave][k][4 * lj + j] = q[k][j];
     }
     __syncthreads();
     if (tid < 48) {
       const int k = tid >> 4, c = tid & 15;
-      const float t = sstat[0][k][c] + sstat[1][k][c] + sstat[2][k][c] + sstat[3][k][c];
-      if (a.epi_partial) a.epi_partial[((size_t)mt * 3 + k) * a.Cout + g * 16 + c] = t;
-      if (ba.bw_st_acc) __builtin_amdgcn_global_atomic_fadd_f64(ba.bw_st_acc + ((size_t)(b % ba.nrep) * a.Cout + g * 16 + c) * 4 + k, (double)t);
+      const double t = ((sbw[0][k][c] + sbw[1][k][c]) + sbw[2][k][c]) + sbw[3][k][c];
+      if (a.epi_partial) a.epi_partial[((size_t)mt * 3 + k) * a.Cout + g * 16 + c] = (float)t;
+      if (ba.bw_st_acc) __builtin_amdgcn_global_atomic_fadd_f64(ba.bw_st_acc + ((size_t)(b % ba.nrep) * a.Cout + g * 16 + c) * 4 + k, t);
     }
   }
 }

@@ -97,9 +97,11 @@ __global__ __launch_bounds__(NT) void maxpool_relu_bwd_kernel(const float* __res
 __global__ __launch_bounds__(NT) void clamp_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pre,
                                                        float* __restrict__ out, float* __restrict__ partial, int B, int C,
                                                        int H, int W) {
-  __shared__ float red[NT / 64];
+  // column sums in fp64 (here and in colsum_finalize_kernel), as torch's CPU reductions accumulate them (acc_type<float> = double):
+  // the bias gradient is a signed sum over every pixel of the batch; the cost is not measurable (the kernel is bound by its loads)
+  __shared__ double red[NT / 64];
   const int64_t hw = (int64_t)H * W, npx = (int64_t)B * hw;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int64_t p = blockIdx.x * (int64_t)NT + threadIdx.x; p < npx; p += (int64_t)gridDim.x * NT) {
     const int64_t b = p / hw, r = p - b * hw;
     for (int c = 0; c < C; ++c) {
@@ -107,23 +109,23 @@ __global__ __launch_bounds__(NT) void clamp_bwd_kernel(const float* __restrict__
       const float pv = pre[s];
       const float v = (pv >= 0.f && pv <= 1.f) ? g[s] : 0.f;
       out[p * C + c] = v;
-      if (c < 4) acc[c] += v;
+      if (c < 4) acc[c] += (double)v;
     }
   }
   for (int c = 0; c < C && c < 4; ++c) {
-    const float t = block_sum<NT>(acc[c], red);
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * C + c] = t;
+    const double t = block_sum_d<NT>(acc[c], red);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * C + c] = (float)t;
   }
 }
 
 __global__ __launch_bounds__(NT) void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                              int nblk, int C, int accumulate) {
-  __shared__ float red[NT / 64];
+  __shared__ double red[NT / 64];
   const int c = blockIdx.x;
-  float t = 0.f;
-  for (int b = threadIdx.x; b < nblk; b += NT) t += partial[(size_t)b * C + c];
-  t = block_sum<NT>(t, red);
-  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + t : t;
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += NT) t += (double)partial[(size_t)b * C + c];
+  t = block_sum_d<NT>(t, red);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)t : (float)t;
 }
 
 // ---- pixel criterion: mode 0 = MSE, 1 = L1.  Two-stage fixed-order reduction (last block finishes).
