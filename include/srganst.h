@@ -68,6 +68,8 @@ long sst_debug_band_launches(void);       /* test hook: launches of the band con
 long sst_debug_wgrad_band_launches(void); /* test hook: launches of the all-taps weight-gradient kernel so far */
 /* measurement hook (tools/mfma_peak.py): `blocks` workgroups x 4 waves x iters x 4 v_mfma_f32_32x32x2_f32, no memory traffic */
 int sst_debug_mfma_peak(float* out, int blocks, int iters, void* stream);
+/* measurement hook (tools/stamp_step.py): out[slot] = the device's 100 MHz wall clock at the point of the stream / captured graph */
+int sst_debug_stamp(unsigned long long* out, int slot, void* stream);
 int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,
                  const float* in_scale, const float* in_shift, const float* in_slope,
                  float in_slope_const, int in_act, const float* residual, float* stats,

@@ -52,3 +52,14 @@ SST_API int sst_debug_mfma_peak(float* out, int blocks, int iters, void* stream)
   SST_LAUNCH_CHECK("mfma_peak_kernel");
   return SST_OK;
 }
+
+// ---- measurement hook (tools/stamp_step.py): one thread writes the device's constant-rate wall clock (100 MHz) into out[slot].
+// Dropped into a captured step at the points of interest, it shows when each branch of the launch DAG really starts and ends in
+// an UNPROFILED replay (the profiler's own launch overhead moves exactly those points).
+__global__ void stamp_kernel(unsigned long long* out, int slot) { out[slot] = wall_clock64(); }
+SST_API int sst_debug_stamp(unsigned long long* out, int slot, void* stream) {
+  SST_REQUIRE(out && slot >= 0, "sst_debug_stamp: bad argument");
+  stamp_kernel<<<1, 1, 0, sst_stream(stream)>>>(out, slot);
+  SST_LAUNCH_CHECK("stamp_kernel");
+  return SST_OK;
+}

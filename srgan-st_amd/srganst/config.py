@@ -109,6 +109,12 @@ class Config:
         self.KERNEL.D_TWO_STREAMS = os.environ.get("SST_D_TWO_STREAMS", "0") != "0"
         # the discriminator step beside the generator's backward, whole iteration = one graph (engine.TrainEngine._iter_gd)
         self.KERNEL.OVERLAP_GD = os.environ.get("SST_OVERLAP_GD", "1") != "0"
+        # the discriminator step's D(sr.detach()) forward (train.py:158) is not run again: it repeats the generator step's D(sr)
+        # (same input, same weights, deterministic kernels); its running-statistics side effects are replayed (disc_graph.replay_running_stats)
+        # D(gt)'s forward starts with the iteration, beside the generator's forward (running statistics replayed in the reference's order).
+        # Off: measured 5.44 vs 5.36 ms - two conv-bound passes side by side just take turns (G forward + D(sr): 1.30 -> 1.84 ms)
+        self.KERNEL.EARLY_D_GT = os.environ.get("SST_EARLY_D_GT", "0") != "0"
+        self.KERNEL.REUSE_D_SR = os.environ.get("SST_REUSE_D_SR", "1") != "0"
         self.KERNEL.LR_ON_DEVICE = False    # True: the LR batch is synthesised from the GT batch on the GPU (sst_bicubic, same
                                             # values as dataset.py:28 on the 1/255 grid) instead of taking the loader's copy
 

@@ -50,11 +50,15 @@ def _packs(module, p, with_dgrad):
     return wp, wd, ws2
 
 
-def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook=None):
+def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook=None, update_running=True):
     """bump_counters=False: the caller has already added this pass to num_batches_tracked (two passes on two streams must
     not race on the counters).  bn_hook(li, when) is called right before ("pre") / after ("post") each train-mode
     bn_finalize - the only kernels of a forward that write shared state (running statistics): a caller that runs two passes
-    concurrently orders them there."""
+    concurrently orders them there.  update_running=False: the pass leaves the running statistics and the batch counter alone;
+    the caller applies them later, in the reference's order, with replay_running_stats (a pass that runs EARLIER than its place
+    in the reference's sequence)."""
+    if not update_running:
+        bump_counters = False
     sv = {"layers": []}
     wp, sv["wd"], sv["ws2"] = _packs(module, p, need_grad)
     if training and bump_counters:
@@ -74,10 +78,12 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
             if training:
                 if bn_hook is not None:
                     bn_hook(len(sv["layers"]), "pre")
-                mean, rstd, scale, shift = ops.bn_finalize(st, cnt, g, b, bn.running_mean, bn.running_var)
+                mean, rstd, scale, shift = ops.bn_finalize(st, cnt, g, b, bn.running_mean if update_running else None,
+                                                           bn.running_var if update_running else None)
                 if bn_hook is not None:
                     bn_hook(len(sv["layers"]), "post")
                 rec["mean"], rec["rstd"] = mean, rstd
+                rec["st"], rec["cnt"] = st, cnt             # replay_running_stats
             else:
                 scale, shift = ops.bn_eval_affine(g, b, bn.running_mean, bn.running_var)
         else:
@@ -90,6 +96,22 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
     out = ops.head_fwd(h1, p["classifier.2.weight"], p["classifier.2.bias"], LRELU)
     sv["flat"], sv["h1"] = flat, h1
     return out, sv
+
+
+def replay_running_stats(module, p, sv):
+    """The side effects of ONE MORE train-mode forward over the input and weights of the pass saved in `sv`, without running it:
+    every kernel of the forward is deterministic, so the second pass would reproduce the saved activations bit for bit - all it
+    would add is one more step of the BatchNorm running statistics (same batch statistics: bn_finalize again on the saved
+    per-tile partials, i.e. the very launch the forward would issue) and of num_batches_tracked.  engine.TrainEngine uses it for
+    the discriminator step's D(sr.detach()) (train.py:158), which repeats the generator step's D(sr) (train.py:136) before any
+    weight has changed."""
+    ops.flatten_bn_counters(module).add_(1)
+    for rec in sv["layers"]:
+        if rec["bi"] is None:
+            continue
+        bn = module.features[rec["bi"]]
+        ops.bn_finalize(rec["st"], rec["cnt"], p[f"features.{rec['bi']}.weight"], p[f"features.{rec['bi']}.bias"],
+                        bn.running_mean, bn.running_var)
 
 
 def _grad_views(module, p, need_param_grads):
@@ -212,6 +234,9 @@ class DiscriminatorFn(torch.autograd.Function):
         if need_grad and not module.training:
             raise NotImplementedError("Discriminator backward in eval() mode is not on the reference's path (train.py:110)")
         out, sv = forward(module, x, p, module.training, need_grad)
+        if module.__dict__.get("_keep_pass") and need_grad and module.training:
+            # the step engine re-uses this pass (replay_running_stats): input identity, logits, saved activations
+            module.__dict__["_last_pass"] = {"x_ptr": x.data_ptr(), "x_shape": tuple(x.shape), "out": out, "sv": sv, "p": p}
         if need_grad:
             ctx.module, ctx.sv, ctx.p, ctx.names = module, sv, p, names
             ctx.need_param, ctx.need_dx = need_param, need_dx

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from . import dist as sdist
@@ -111,6 +113,9 @@ class _GraphedStep:
             gc.disable()
             try:
                 g = torch.cuda.CUDAGraph()
+                dot = os.environ.get("SST_GRAPH_DOT")       # dev: directory for hipGraphDebugDotPrint dumps of every captured graph
+                if dot:
+                    g.enable_debug_mode()
                 # thread_local: calls made by OTHER threads during capture (e.g. the RCCL watchdog polling its events)
                 # must not invalidate it
                 # a capture stream of its own: torch's shared default capture stream would stay dead for every later capture
@@ -118,6 +123,8 @@ class _GraphedStep:
                 with torch.cuda.graph(g, stream=torch.cuda.Stream(), capture_error_mode="thread_local"):
                     self.out = self.fn()
                 self.graph = g
+                if dot:
+                    g.debug_dump(os.path.join(dot, f"graph_{getattr(self.fn, '__name__', 'fn')}_{id(self):x}.dot"))
             except Exception as e:  # keep training (eager) rather than die: a step is still the same kernels
                 import sys
                 print(f"[srganst] hipGraph capture failed ({type(e).__name__}: {e}); the whole engine continues in eager mode",
@@ -308,9 +315,11 @@ class TrainEngine:
             p.requires_grad = False
         self.g_opt.zero_grad(set_to_none=True)
         self.D.__dict__["_packs_fresh"] = False
+        self.D.__dict__["_keep_pass"], self.D.__dict__["_last_pass"] = True, None      # _d_fwd_cls re-uses the D(sr) pass
         sr = self.G(self.lr)
         total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
                                        adversarial=lambda crit: crit(self.D(sr), self.real))
+        self.D.__dict__["_keep_pass"] = False
         self.sr = sr.detach()
         self.loss_values = vals
         self._g_total = total
@@ -356,17 +365,41 @@ class TrainEngine:
     # -- discriminator half without autograd, in two parts (data-parallel overlap).  Same kernels with the same arguments as
     # the autograd path above, in an order that keeps every parameter's accumulation order (autograd runs the D(sr) pass
     # before the D(gt) pass: loss_fake was recorded last), so the gradients are bit-identical.
-    def _d_fwd_cls(self):
+    def _d_gt_fwd(self):
+        """D(gt)'s forward ahead of its place in the reference's sequence (it needs nothing of the generator): running statistics
+        and batch counter untouched - _d_fwd_cls replays them where the reference has the pass (after the generator step's D(sr))."""
+        from . import disc_graph
+        D = self.D
+        names = [n for n, _ in D.named_parameters()]
+        pd = dict(zip(names, [t.detach() for t in D.parameters()]))
+        pred_gt, sv_gt = disc_graph.forward(D, self.gt, pd, True, True, update_running=False)
+        return pd, pred_gt, sv_gt
+
+    def _d_fwd_cls(self, early_gt=None):
         from . import disc_graph, ops
         D = self.D
         for p in D.parameters():
             p.requires_grad = True
         self.d_opt.zero_grad(set_to_none=True)
         names = [n for n, _ in D.named_parameters()]
-        pd = dict(zip(names, [t.detach() for t in D.parameters()]))
-        pred_gt, sv_gt = disc_graph.forward(D, self.gt, pd, True, True)
+        if early_gt is not None:
+            pd, pred_gt, sv_gt = early_gt
+            disc_graph.replay_running_stats(D, pd, sv_gt)
+        else:
+            pd = dict(zip(names, [t.detach() for t in D.parameters()]))
+            pred_gt, sv_gt = disc_graph.forward(D, self.gt, pd, True, True)
         loss_real, dl_gt = ops.bce_logits(pred_gt, self.real, want_loss=True, want_grad=True)
-        pred_sr, sv_sr = disc_graph.forward(D, self.sr, pd, True, True)
+        # D(sr.detach()) (train.py:158) repeats the generator step's D(sr) (train.py:136): same input, same weights (D's Adam comes
+        # after both), train-mode BatchNorm both times - every kernel is deterministic, so the pass would reproduce the saved
+        # activations and logits bit for bit.  It is not run again: its side effects (running statistics, batch counter) are
+        # replayed in the reference's order (after D(gt)'s) and the backward works on the generator step's saved pass.
+        kept = D.__dict__.pop("_last_pass", None) if self.config.KERNEL.REUSE_D_SR else None
+        if (kept is not None and kept["x_ptr"] == self.sr.data_ptr() and kept["x_shape"] == tuple(self.sr.shape)
+                and all(kept["p"][n].data_ptr() == pd[n].data_ptr() and kept["p"][n]._version == pd[n]._version for n in names)):
+            disc_graph.replay_running_stats(D, pd, kept["sv"])
+            pred_sr, sv_sr = kept["out"], kept["sv"]
+        else:
+            pred_sr, sv_sr = disc_graph.forward(D, self.sr, pd, True, True)
         loss_fake, dl_sr = ops.bce_logits(pred_sr, self.fake, want_loss=True, want_grad=True)
         self.d_loss, self.pred_gt, self.pred_sr = loss_real + loss_fake, pred_gt, pred_sr
         D.__dict__["_grad_accum"] = {"flat": None}
@@ -456,23 +489,45 @@ class TrainEngine:
             p.requires_grad = False
         self.g_opt.zero_grad(set_to_none=True)
         self.D.__dict__["_packs_fresh"] = False
-        sr = self.G(self.lr)
-        total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
-                                       adversarial=lambda crit: crit(self.D(sr), self.real))
-        self.sr = sr.detach()
+        self.D.__dict__["_keep_pass"], self.D.__dict__["_last_pass"] = True, None
+        from . import disc_graph, ops
+        ops.debug_stamp(0)
         main = torch.cuda.current_stream()
         if self._side_d is None:
             self._side_d = torch.cuda.Stream()
+        early_gt = None
+        if cfg.KERNEL.EARLY_D_GT and "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS:
+            # D(gt)'s forward beside the generator's forward (a chain of short launches): the weights are packed here, on the main
+            # stream, for all three passes of the iteration
+            names = [n for n, _ in self.D.named_parameters()]
+            disc_graph._packs(self.D, dict(zip(names, [t.detach() for t in self.D.parameters()])), True)
+            self._side_d.wait_stream(main)
+            with torch.cuda.stream(self._side_d):
+                early_gt = self._d_gt_fwd()
+        sr = self.G(self.lr)
+        ops.debug_stamp(1)
+        total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
+                                       adversarial=lambda crit: crit(self.D(sr), self.real))
+        self.D.__dict__["_keep_pass"] = False
+        self.sr = sr.detach()
+        ops.debug_stamp(2)
         self._side_d.wait_stream(main)
         with torch.cuda.stream(self._side_d):   # both passes on ONE side stream: a third concurrent branch (the two passes on two
-            self._d_fwd_cls()                   # streams, as _d_two_stream does on its own) crashed hipStreamEndCapture (ROCm 7.2)
+            ops.debug_stamp(3)
+            self._d_fwd_cls(early_gt)           # streams, as _d_two_stream does on its own) crashed hipStreamEndCapture (ROCm 7.2)
+            ops.debug_stamp(4)
             self._d_features()
+            ops.debug_stamp(5)
+        ops.debug_stamp(6)
         with torch.autograd.set_multithreading_enabled(False):      # backward on this thread: one thread feeds the open capture
             total.backward(_one(total))
+        ops.debug_stamp(7)
         self.loss_values = vals
         self.g_opt.step()
+        ops.debug_stamp(8)
         main.wait_stream(self._side_d)
         self._d_step()
+        ops.debug_stamp(9)
         return vals
 
     def _d_two_stream_full(self):

@@ -924,3 +924,20 @@ class WgradGroup:
             _trace(name, flops,
                    lambda args=args: _abi.lib().sst_conv_wgrad_grouped(*args, stream_ptr()), js, slab, arr)
         self.jobs = []
+
+
+_STAMPS = {}
+
+
+def debug_stamp(slot):
+    """Dev (SST_STAMP=1, tools/stamp_step.py): the device wall clock at this point of the current stream -> debug_stamps()[slot]."""
+    if os.environ.get("SST_STAMP", "0") == "0":
+        return
+    dev = torch.cuda.current_device()
+    if dev not in _STAMPS:
+        _STAMPS[dev] = torch.zeros(64, dtype=torch.int64, device="cuda")
+    check(_abi.lib().sst_debug_stamp(ptr(_STAMPS[dev]), int(slot), stream_ptr()), "sst_debug_stamp")
+
+
+def debug_stamps():
+    return _STAMPS.get(torch.cuda.current_device())

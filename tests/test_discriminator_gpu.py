@@ -338,9 +338,9 @@ def test_train_engine_schedules_are_bit_identical(interval):
     from srganst.loss import MSELoss, StructureTensorLoss
     from srganst.model import Discriminator, Generator
 
-    def run(gd, two, use_graph):
+    def run(gd, two, use_graph, reuse=True, early=True):
         cfg = make_cfg(16, 2, 8)
-        cfg.KERNEL.OVERLAP_GD, cfg.KERNEL.D_TWO_STREAMS = gd, two
+        cfg.KERNEL.OVERLAP_GD, cfg.KERNEL.D_TWO_STREAMS, cfg.KERNEL.REUSE_D_SR, cfg.KERNEL.EARLY_D_GT = gd, two, reuse, early
         torch.manual_seed(1)
         D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
         cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
@@ -360,7 +360,13 @@ def test_train_engine_schedules_are_bit_identical(interval):
 
     ref = run(False, False, False)                      # sequential, eager
     assert int(ref["D.features.3.num_batches_tracked"]) == 8 + 2 * (8 // interval)
-    for gd, two, use_graph in ((False, False, True), (False, True, False), (False, True, True), (True, False, False), (True, False, True)):
-        out = run(gd, two, use_graph)
+    # the merged schedule does not run D(sr.detach()) again (KERNEL.REUSE_D_SR: the generator step's D(sr) pass is re-used and the
+    # running statistics replayed) - with and without that, against the sequential schedule that runs all three passes
+    # ... and starts D(gt)'s forward with the iteration (KERNEL.EARLY_D_GT, statistics replayed in the reference's order)
+    for gd, two, use_graph, reuse, early in ((False, False, True, True, True), (False, True, False, True, True), (False, True, True, True, True),
+                                             (True, False, False, True, True), (True, False, True, True, True),
+                                             (True, False, False, False, False), (True, False, True, False, False),
+                                             (True, False, True, True, False), (True, False, True, False, True)):
+        out = run(gd, two, use_graph, reuse, early)
         for k in ref:
-            assert torch.equal(ref[k], out[k]), (gd, two, use_graph, k)
+            assert torch.equal(ref[k], out[k]), (gd, two, use_graph, reuse, early, k)
