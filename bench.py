@@ -45,8 +45,12 @@ def workload_name(workload, hr, B):
     return WORKLOADS[workload][0].replace("hr96", f"hr{hr}").replace("_b16_", f"_b{B}_")
 
 
-def flop_per_image(workload, hr):
+def flop_per_image(workload, hr, d_sr_reused=False):
+    """FLOP the step EXECUTES per image.  d_sr_reused: the discriminator step's D(sr.detach()) forward is shared with the generator
+    step's D(sr) (engine.TrainEngine, KERNEL.REUSE_D_SR: bit-identical results) - one discriminator forward less than the reference runs."""
     g, d, v = WORKLOADS[workload][1]
+    if d_sr_reused:
+        d -= 1
     return 2.0 * (g * G_FWD_MAC_PER_IMG + d * D_FWD_MAC_PER_IMG + v * VGG_FWD_MAC_PER_IMG) * (hr / 96.0) ** 2
 
 
@@ -346,6 +350,7 @@ def main():
     el = timed_steps(eng, gt, lr, args.steps, args.warmup, world, device)
     losses = {k: float(v) for k, v in eng.loss_values.items()}
     graph_active = bool(eng.graph_active)         # what actually happened, not the flag: a failed capture falls back to eager
+    d_sr_reused = bool(getattr(eng, "d_sr_reused", False))
     eng.close()
 
     out = None
@@ -360,7 +365,9 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl, "global_batch": B * world, "hr": args.hr, "lr": args.hr // 4,
                           "parallelism": f"dp{world}", "hip_graph": graph_active, "d_update_interval": 1 if args.workload != "srresnet" else None,
-                          "step_tflops": flop_per_image(args.workload, args.hr) * imgs / 1e12, "losses_last_step": losses}}
+                          "d_sr_forward": ("shared with the generator step's D(sr) pass (same input and weights, bit-identical; SST_REUSE_D_SR=0 runs it again)"
+                                           if d_sr_reused else ("run" if args.workload != "srresnet" else None)),
+                          "step_tflops": flop_per_image(args.workload, args.hr, d_sr_reused) * imgs / 1e12, "losses_last_step": losses}}
     if args.workload == "srgan" and not args.no_secondary:
         # BASELINE configs[1] (SRResNet, G only) in the same run, same protocol, fewer steps; at every N, so the driver's
         # scaling runs also exercise the generator-only gradient all-reduce.

@@ -259,6 +259,7 @@ class TrainEngine:
         # ([fwd+bwd] -> all-reduce -> wait -> [Adam] per network); both give bit-identical parameters (tests/test_dp_gpu.py).
         self.overlap = self.dp and (config.DIST.OVERLAP_COMM if overlap_comm is None else overlap_comm)
         self._d_a = self._d_b = self._g_f = self._g_b = None
+        self.d_sr_reused = False         # set once the discriminator step has run on the generator step's D(sr) pass (KERNEL.REUSE_D_SR)
         self._side = self._side_d = None
         self._it = None
         if self.dp:
@@ -398,6 +399,7 @@ class TrainEngine:
                 and all(kept["p"][n].data_ptr() == pd[n].data_ptr() and kept["p"][n]._version == pd[n]._version for n in names)):
             disc_graph.replay_running_stats(D, pd, kept["sv"])
             pred_sr, sv_sr = kept["out"], kept["sv"]
+            self.d_sr_reused = True
         else:
             pred_sr, sv_sr = disc_graph.forward(D, self.sr, pd, True, True)
         loss_fake, dl_sr = ops.bce_logits(pred_sr, self.fake, want_loss=True, want_grad=True)

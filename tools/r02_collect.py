@@ -5,6 +5,13 @@ which bench.py also reads), rocprofv3 kernel-stats CSVs, SQ counter summaries.""
 import glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
+# gpurun merges every refresh into the same local directories: keep only the newest run's files in each
+for d in glob.glob("gpurun_out/r02f_*/*/"):
+    fs = glob.glob(d + "*")
+    newest = max(os.path.getmtime(f) for f in fs)
+    for f in fs:
+        if os.path.getmtime(f) < newest - 600:
+            os.remove(f)
 run = lambda *a: subprocess.run([sys.executable, *a], check=True, capture_output=True, text=True).stdout
 for wl in ("srgan", "srresnet"):
     print(run("tools/pmc_summarize.py", wl, f"gpurun_out/r02f_pmc_fetch_{wl}", f"gpurun_out/r02f_pmc_write_{wl}"))
