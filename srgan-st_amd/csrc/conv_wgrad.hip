@@ -587,6 +587,255 @@ static void launch_wgrad_reduce(const float* slab, float* dw, int nchunk, int KK
   wgrad_reduce_kernel<<<dim3(rb, njobs), 256, 0, st>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate, grouped, t);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3x3 / STRIDE-2 / pad-1 weight gradient, ALL 9 TAPS per wave (discriminator layers 2 / 4 / 6 / 8, reference model.py:34-59).
+//   dW[co][ci][ky][kx] = sum_{b,oy,ox} dY[b,oy,ox,co] * act(X)[b, 2oy+ky-1, 2ox+kx-1, ci]
+// GEMM view per tap: M = co, N = ci, K = output pixels.  The per-tap kernel (conv_wgrad_kernel) re-stages X for each of the 9
+// taps and ran these layers at 30 % of the MFMA peak; the stride-1 all-taps form (conv_wgrad_band_kernel: a 64 x 64 block x 9
+// taps per WORKGROUP, K split over workgroups) cannot take them either - a stride-2 X patch is 4.8x the dY tile, a band of whole
+// rows does not fit the LDS at 96 / 48 px, and 512 workgroups x 147 KB of partials are 75 MB of slab per launch whatever the layer.
+// Here the split is turned round:
+//   * a WORKGROUP owns ONE 32 (co) x 32 (ci) block for all 9 taps and a contiguous range of pixel tiles; its 8 WAVES split K:
+//     wave w takes tiles w, w+8, ... of the range, each with 9 accumulators (144 registers) = the whole block;
+//   * a tile is TH x TW output pixels (2x8 or 2x6 - never across an image), its X patch (2TH+1) x (2TW+1) pixels x 32
+//     channels and its dY tile live in a WAVE-PRIVATE LDS region: no workgroup barrier in the main loop.  The next tile's global
+//     loads are issued before the current tile's MFMA loop and consumed (BatchNorm affine + LeakyReLU of the producer applied,
+//     padding zeroed) behind it; the MFMA loop is fully unrolled, every LDS offset an immediate, the operands of K step ks+1 are
+//     read before the 9 MFMAs of step ks are issued;
+//   * the waves' partial blocks are summed through LDS at the end (tap by tap, double-buffered: one barrier per tap), so a
+//     workgroup emits ONE 32 x 32 x 9 partial: (Cout/32)(Cin/32) x nchunk x 36.9 KB of slab per launch - 9.4 MB with ~256
+//     workgroups instead of 75 MB, and no K split over workgroups at all for the 512-channel layer.  wgrad_reduce_kernel sums the
+//     chunks in fixed order.
+// Measured (tools/time_wgrad_s2.py, B = 16, incl. the slab reduce): 96 px 46 us (per-tap kernel 51), 48 px 43 (54), 24 px 44 (57),
+// 12 px 52 (66).  Where a launch goes (SST_WGRAD_S2_DBG ablation, 48-px layer): launch + slab reduce 6, first loads 3.5, MFMA loop
+// 21 (= the MFMA rate), staging 4.5, exchange 5-7 - strictly additive: the two waves of a SIMD do not hide each other's phases
+// (de-phasing them with a head start changed nothing), 4 waves x 4x8 tiles with 512 registers each measured 49-65 us, fewer VALU
+// instructions in the staging (interior / edge instantiations, LeakyReLU as max) and LDS operand prefetch changed nothing.
+struct WgS2Args {
+  const float* x; const float* dy; float* slab;
+  const float* in_scale; const float* in_shift; const float* in_slope; float in_slope_const; int in_act;
+  int B, H, W, Cin, Cout, Ho, Wo;
+  int tiles_x, tiles_img, ntiles, tpc;          // tiles per row of tiles / per image / in total / per chunk
+  int dbg;                                      // ablation bits (SST_WGRAD_S2_DBG, dev): 1 no staging stores, 2 no global loads, 4 no MFMA loop, 8 no exchange
+};
+
+// S2_NW waves per workgroup: 8 = two per SIMD, one stages while the other multiplies (256 registers each); 4 = one per SIMD with
+// 512 registers (room for the scheduler to read LDS operands ahead)
+template <int TH, int TW, int S2_NW>
+struct WgS2Geom {
+  static constexpr int NPIX = TH * TW, PH = 2 * TH + 1, PW = 2 * TW + 1, NPX = PH * PW;
+  static constexpr int XQ = (NPX * 8 + 63) / 64;           // 16-B quads per lane: X patch (8 quads = 32 channels per pixel)
+  static constexpr int DQ = (NPIX * 8 + 63) / 64;          //                       dY tile
+  static constexpr int WAVE_FLOATS = (XQ * 8 + DQ * 8) * 32;    // one wave's private region: [patch pixel slot][32 ci] then [tile pixel slot][32 co]
+  static constexpr size_t LDS_BYTES = (size_t)S2_NW * WAVE_FLOATS * sizeof(float);
+  static_assert(NPIX % 2 == 0 && TW % 2 == 0, "pixel pairs of one tile row");
+  static_assert((size_t)2 * S2_NW * 32 * 33 * sizeof(float) <= LDS_BYTES, "exchange scratch (double-buffered) fits the staging area");
+};
+
+template <int TH, int TW, int S2_NW>
+__global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_s2_kernel(WgS2Args a) {
+  using G = WgS2Geom<TH, TW, S2_NW>;
+  constexpr int NPIX = G::NPIX, PW = G::PW, NPX = G::NPX, XQ = G::XQ, DQ = G::DQ;
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  float* const xs = wlds + wave * G::WAVE_FLOATS;        // X patch
+  float* const ds = xs + XQ * 8 * 32;                    // dY tile
+  const int nci = a.Cin >> 5;
+  const int co0 = (blockIdx.y / nci) * 32, ci0 = (blockIdx.y % nci) * 32;
+  const int t0 = blockIdx.x * a.tpc, t1 = min(a.ntiles, t0 + a.tpc);
+  const float slope = a.in_slope ? a.in_slope[0] : a.in_slope_const;
+  const int q4 = (lane & 7) * 4;                         // this lane's channel quad inside the 32-channel slice
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // Staging comes in two instantiations chosen per tile (wave-uniform): INTERIOR tiles (no padding pixel in the patch: 4 of 5) need
+  // no address selects and no zeroing; EDGE tiles (first tile row / column of an image) mask the top row / left column.  VALU work
+  // matters here beyond its own time: on this chip it does not run under another wave's MFMAs (the SQ counters of every conv
+  // kernel show VALU-active + MFMA-busy < 100 %, and this kernel's phases measured strictly additive).
+  f32x4 xr[XQ], dr[DQ];
+  unsigned okm = 0;
+  bool edge = false;                                     // of the tile whose loads are in xr
+  const bool lmax = a.in_act == ACT_SLOPE && slope >= 0.f && slope <= 1.f;       // LeakyReLU as max(v, slope * v)
+  auto issue = [&](int t, auto edge_) {
+    constexpr bool EDGE = decltype(edge_)::value;
+    const int b = t / a.tiles_img, rem = t - b * a.tiles_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    // origin of the patch (EDGE: may lie one row / one column outside the image: those quads are masked), < 2^31 floats (host check)
+    const int xo = ((b * a.H + 2 * oy0 - 1) * a.W + 2 * ox0 - 1) * a.Cin + ci0 + q4;
+    const float* db = a.dy + ((size_t)(b * a.Ho + oy0) * a.Wo + ox0) * a.Cout + co0 + q4;
+    okm = 0;
+#pragma unroll
+    for (int u = 0; u < XQ; ++u) {
+      const int p = (lane >> 3) + 8 * u;
+      const int pr = p / PW, pc = p - pr * PW;
+      bool ok = 8 * u + 7 < NPX || p < NPX;              // slots past the patch exist in the last quad only (compile-time for the others)
+      if (EDGE) ok = ok && (pr > 0 || oy0 > 0) && (pc > 0 || ox0 > 0);           // bottom / right never leave the image (H, W even)
+      const int off = xo + (pr * a.W + pc) * a.Cin;
+      xr[u] = *reinterpret_cast<const f32x4*>(a.x + ((EDGE || 8 * u + 7 >= NPX) ? (ok ? off : ci0 + q4) : off));
+      if (EDGE) okm |= ok ? (1u << u) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < DQ; ++u) {
+      const int p = (lane >> 3) + 8 * u;
+      const int py = p / TW, px = p - py * TW;
+      dr[u] = *reinterpret_cast<const f32x4*>(db + ((8 * u + 7 < NPIX || p < NPIX) ? (py * a.Wo + px) * a.Cout : 0));
+    }
+  };
+  auto is_edge = [&](int t) {
+    const int rem = t % a.tiles_img;
+    return rem < a.tiles_x || rem % a.tiles_x == 0;
+  };
+  auto issue_any = [&](int t) {
+    edge = is_edge(t);
+    if (edge) issue(t, std::true_type{}); else issue(t, std::false_type{});
+  };
+  // registers -> this wave's LDS region.  The patch region has XQ * 8 >= NPX pixel slots and the dY region DQ * 8 >= NPIX, so
+  // every lane stores unconditionally
+  auto store = [&](auto edge_) {
+    constexpr bool EDGE = decltype(edge_)::value;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};      // re-read per tile (cache hits): 8 registers not held across the K loop
+    if (a.in_scale) {
+      sc = *reinterpret_cast<const f32x4*>(a.in_scale + ci0 + q4);
+      sh = *reinterpret_cast<const f32x4*>(a.in_shift + ci0 + q4);
+    }
+#pragma unroll
+    for (int u = 0; u < XQ; ++u) {
+      const int p = (lane >> 3) + 8 * u;
+      f32x4 v = xr[u];
+      if (a.in_scale) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+      }
+      if (lmax) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], v[j] * slope);
+      } else if (a.in_act == ACT_SLOPE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+      }
+      if (EDGE && !((okm >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // padding stays exactly zero
+      *reinterpret_cast<f32x4*>(xs + p * 32 + q4) = v;
+    }
+#pragma unroll
+    for (int u = 0; u < DQ; ++u) *reinterpret_cast<f32x4*>(ds + ((lane >> 3) + 8 * u) * 32 + q4) = dr[u];
+  };
+
+  int t = t0 + wave;
+  if (t < t1 && !(a.dbg & 2)) issue_any(t);
+  // per-lane fragment bases: lane (li = m or n, lh = k): dY pixel 2*ks + lh, X patch pixel const(ks, tap) + 2*lh
+  const float* const dl = ds + lh * 32 + li;
+  const float* const xl = xs + 2 * lh * 32 + li;
+  for (; t < t1; t += S2_NW) {
+    // (the previous tile's MFMA loop has issued all its LDS reads: LDS ops of a wave complete in order)
+    if (!(a.dbg & 1)) {
+      if (edge) store(std::true_type{}); else store(std::false_type{});
+    }
+    if (t + S2_NW < t1 && !(a.dbg & 2)) issue_any(t + S2_NW);            // in flight during the MFMA loop below
+    if (a.dbg & 4) continue;
+    // ---- K loop: pixel pairs (2ks, 2ks+1) of the tile (TW even: same tile row), 9 taps each
+    // Operands of step ks+1 are read from LDS BEFORE the 9 MFMAs of step ks are issued (scheduling barriers keep that order: left
+    // alone, hipcc reads each operand 1-3 MFMAs ahead of its use and waits lgkmcnt(0) every other MFMA - measured 42 us per layer)
+    float av, bv[9];
+    auto fetch = [&](int ks, float& a_, float (&b_)[9]) {
+      const int py = (2 * ks) / TW, px = (2 * ks) % TW;
+      a_ = dl[2 * ks * 32];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) b_[tap] = xl[((2 * py + tap / 3) * PW + 2 * px + tap % 3) * 32];
+    };
+    fetch(0, av, bv);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < NPIX / 2; ++ks) {
+      float an = 0.f, bn[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (ks + 1 < NPIX / 2) fetch(ks + 1, an, bn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[tap], acc[tap], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      av = an;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) bv[tap] = bn[tap];
+    }
+  }
+
+  // ---- the waves' K-partials -> one 32 x 32 block per tap (through LDS, fixed order); wave w then owns rows 4w .. 4w+3
+  if (a.dbg & 8) {
+    if (acc[0][0] == 12345.f) a.slab[0] = 1.f;
+    return;
+  }
+  // [2][wave][row 32][33] at the start of the staging area, double-buffered: round r writes buffer r & 1, so ONE barrier per round
+  // is enough (a wave reaches the barrier of round r + 1 only after its reads of round r, and buffer r & 1 is next written in round r + 2)
+  float* const scr = wlds;
+  float* const out = a.slab + (size_t)blockIdx.x * 9 * a.Cout * a.Cin;
+  __syncthreads();                                       // every wave has left its main loop (the scratch overlays the staging area)
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    float* const sb = scr + (tap & 1) * (S2_NW * 32 * 33);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      sb[(wave * 32 + row) * 33 + li] = acc[tap][r];
+    }
+    __syncthreads();
+    constexpr int RPW = 32 / S2_NW;                      // rows of the block per wave
+#pragma unroll
+    for (int j = 0; j < RPW / 2; ++j) {
+      const int row = RPW * wave + (RPW / 2) * lh + j;
+      float v = sb[row * 33 + li];
+#pragma unroll
+      for (int w = 1; w < S2_NW; ++w) v += sb[(w * 32 + row) * 33 + li];
+      out[((size_t)tap * a.Cout + co0 + row) * a.Cin + ci0 + li] = v;
+    }
+  }
+}
+
+// Plan of the stride-2 all-taps kernel: tile shape (th = 0: shape not taken) and number of pixel chunks.
+struct WgS2Plan { int th, tw, nw, nchunk, tpc, ntiles; };
+inline WgS2Plan wgrad_s2_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  WgS2Plan pl{0, 0, 0, 0, 0, 0};
+  if (ksize != 3 || stride != 2 || ((H | W) & 1) || (Cin & 31) || (Cout & 31) || B <= 0) return pl;
+  if (const char* e = getenv("SST_WGRAD_S2")) {
+    if (atoi(e) == 0) return pl;
+  }
+  const int Ho = H / 2, Wo = W / 2;
+  int th = 0, tw = 0, S2_NW = 8;
+  if (const char* e = getenv("SST_WGRAD_S2_NW")) S2_NW = atoi(e) == 4 ? 4 : 8;        // dev
+  if (Wo % 8 == 0 && Ho % 2 == 0) { th = 2; tw = 8; }
+  else if (Wo % 6 == 0 && Ho % 2 == 0) { th = 2; tw = 6; }
+  if (S2_NW == 4 && th && Ho % 4 == 0) th = 4;
+  if (!th || (int64_t)B * H * W * Cin >= (1ll << 31)) return pl;
+  const int ntiles = B * (Ho / th) * (Wo / tw);
+  const int nblk = (Cout >> 5) * (Cin >> 5);
+  // ~one workgroup (8 waves) per CU; a chunk is a multiple of 8 tiles (the waves split it), never less than 8
+  int nchunk = 256 / nblk;
+  if (nchunk < 1) nchunk = 1;
+  int tpc = ((ntiles + nchunk - 1) / nchunk + S2_NW - 1) / S2_NW * S2_NW;
+  if (tpc < S2_NW) tpc = S2_NW;
+  nchunk = (ntiles + tpc - 1) / tpc;
+  pl = WgS2Plan{th, tw, S2_NW, nchunk, tpc, ntiles};
+  return pl;
+}
+
+template <int TH, int TW, int S2_NW>
+static int launch_wgrad_s2_t(const WgS2Args& a, const WgS2Plan& pl, hipStream_t st) {
+  using G = WgS2Geom<TH, TW, S2_NW>;
+  static bool lds_ok = false;
+  if (!lds_ok) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_s2_kernel<TH, TW, S2_NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)G::LDS_BYTES) != hipSuccess)
+      return sst_set_error(SST_ERR_HIP, "conv_wgrad_s2: cannot raise the LDS limit");
+    lds_ok = true;
+  }
+  conv_wgrad_s2_kernel<TH, TW, S2_NW><<<dim3(pl.nchunk, (a.Cout >> 5) * (a.Cin >> 5)), S2_NW * 64, G::LDS_BYTES, st>>>(a);
+  return SST_OK;
+}
+
 static long g_wgrad_band_launches = 0;
 SST_API long sst_debug_wgrad_band_launches(void) { return g_wgrad_band_launches; }   // test hook
 
@@ -617,6 +866,10 @@ static int launch_wgrad_band(WgradArgs& a, const WgBandPlan& pl, int njobs, hipS
 SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
   if (pl.R) return pl.nchunk;
+  if (njobs == 1) {
+    const WgS2Plan p2 = wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride);
+    if (p2.th) return p2.nchunk;
+  }
   const int pad = ksize / 2;
   if (Cin == 3 && ksize == 3 && stride == 1) {         // 3-channel-input kernel (one chunk per band) or the general one
     const int a = B * ((H + C3_ROWS - 1) / C3_ROWS), g = sst_conv_wgrad_chunks(B, H, W, Cin, Cout, ksize);
@@ -629,6 +882,14 @@ SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int k
 SST_API const char* sst_conv_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
   if (pl.R) return ((pl.R + 2) * (W + 2) * 16 + CONV_NT - 1) / CONV_NT <= 7 ? "conv_wgrad_band_kernel<7>" : "conv_wgrad_band_kernel<10>";
+  if (njobs == 1) {
+    const WgS2Plan p2 = wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride);
+    if (p2.th) {
+      static thread_local char nm[48];
+      snprintf(nm, sizeof(nm), "conv_wgrad_s2_kernel<%d, %d, %d>", p2.th, p2.tw, p2.nw);
+      return nm;
+    }
+  }
   if (Cin == 3 && ksize == 3 && stride == 1) return "wgrad_k3c3_kernel";
   return ((Cin & 3) == 0 && (Cout & 3) == 0) ? "conv_wgrad_kernel<true>" : "conv_wgrad_kernel<false>";
 }
@@ -658,10 +919,24 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   const int KK = ksize * ksize;
   dim3 grid(nchunk, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, 1);
+  const WgS2Plan p2 = pl.R ? WgS2Plan{0, 0, 0, 0, 0} : wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride);
   if (pl.R) {
     const int rc = launch_wgrad_band(a, pl, 1, sst_stream(stream), no_tab);
     if (rc != SST_OK) return rc;
     nchunk = pl.nchunk;
+  } else if (p2.th) {
+    WgS2Args s2;
+    s2.x = x; s2.dy = dy; s2.slab = slab; s2.in_scale = in_scale; s2.in_shift = in_shift; s2.in_slope = in_slope;
+    s2.in_slope_const = in_slope_const; s2.in_act = in_act;
+    s2.B = B; s2.H = H; s2.W = W; s2.Cin = Cin; s2.Cout = Cout; s2.Ho = a.Ho; s2.Wo = a.Wo;
+    s2.dbg = getenv("SST_WGRAD_S2_DBG") ? atoi(getenv("SST_WGRAD_S2_DBG")) : 0;
+    s2.tiles_x = a.Wo / p2.tw; s2.tiles_img = (a.Ho / p2.th) * s2.tiles_x; s2.ntiles = p2.ntiles; s2.tpc = p2.tpc;
+    int rc;
+    if (p2.nw == 8) rc = p2.tw == 8 ? launch_wgrad_s2_t<2, 8, 8>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<2, 6, 8>(s2, p2, sst_stream(stream));
+    else if (p2.th == 4) rc = p2.tw == 8 ? launch_wgrad_s2_t<4, 8, 4>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<4, 6, 4>(s2, p2, sst_stream(stream));
+    else rc = p2.tw == 8 ? launch_wgrad_s2_t<2, 8, 4>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<2, 6, 4>(s2, p2, sst_stream(stream));
+    if (rc != SST_OK) return rc;
+    nchunk = p2.nchunk;
   } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && !getenv("SST_WGRAD_NO_K3C3")) {
     nchunk = B * ((H + C3_ROWS - 1) / C3_ROWS);
     const size_t lds = (size_t)(C3_ROWS + 2) * ((W + 2) * 3 + 3) * sizeof(float);

@@ -114,6 +114,9 @@ class Config:
         # D(gt)'s forward starts with the iteration, beside the generator's forward (running statistics replayed in the reference's order).
         # Off: measured 5.44 vs 5.36 ms - two conv-bound passes side by side just take turns (G forward + D(sr): 1.30 -> 1.84 ms)
         self.KERNEL.EARLY_D_GT = os.environ.get("SST_EARLY_D_GT", "0") != "0"
+        # merged iteration: the conv weight gradients of the discriminator's last backward pass run on the generator's stream after its
+        # backward (the discriminator branch is the longer one)
+        self.KERNEL.DEFER_D_WGRAD = os.environ.get("SST_DEFER_D_WGRAD", "1") != "0"
         self.KERNEL.REUSE_D_SR = os.environ.get("SST_REUSE_D_SR", "1") != "0"
         self.KERNEL.LR_ON_DEVICE = False    # True: the LR batch is synthesised from the GT batch on the GPU (sst_bicubic, same
                                             # values as dataset.py:28 on the 1/255 grid) instead of taking the loader's copy

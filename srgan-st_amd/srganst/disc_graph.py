@@ -160,8 +160,11 @@ def backward_classifier(module, p, sv, dout, need_param_grads, st=None):
     return {"views": views, "acc": acc, "grads": grads, "g": g}
 
 
-def backward_features(module, p, sv, st, need_param_grads, need_dx):
-    """Backward of the feature stack (model.py:30-59) of one pass, continuing from backward_classifier's state."""
+def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=None):
+    """Backward of the feature stack (model.py:30-59) of one pass, continuing from backward_classifier's state.
+    defer_wgrad (a list): the conv weight gradients are not launched here - they are leaves of the backward chain (nothing in this
+    pass reads them) - but appended as (event recorded on the current stream once dy exists, launch closure); the caller runs them
+    wherever the chip has room (engine.TrainEngine._iter_gd: on the generator's stream once its backward is done)."""
     views, acc, grads, g = st["views"], st["acc"], st["grads"], st["g"]
 
     def G(name):
@@ -194,9 +197,17 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx):
         part = None
         if wg:
             dwc = G(f"features.{ci}.weight")
-            with ops.SideStream(r["x"], dy, dwc):
+
+            def launch(r=r, dy=dy, dwc=dwc):
                 ops.conv_wgrad(r["x"], dy, dwc, 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
                                in_slope_const=LRELU, in_act=r["x_act"], accumulate=acc)
+            if defer_wgrad is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                defer_wgrad.append((ev, launch, (r["x"], dy, dwc, r["x_scale"], r["x_shift"])))
+            else:
+                with ops.SideStream(r["x"], dy, dwc):
+                    launch()
         if li == 0 and not need_dx:
             break
         xin = r["x"]

@@ -418,11 +418,13 @@ class TrainEngine:
         self._d_flat, self._d_buckets = flat, (flat[cut:total], flat[:cut])
         return self.d_loss
 
-    def _d_features(self):
+    def _d_features(self, defer_gt_wgrad=None):
+        """defer_gt_wgrad (a list): the conv weight gradients of the D(gt) pass are handed back instead of launched
+        (disc_graph.backward_features); they ADD into what the D(sr) pass wrote, which is complete by then on this stream."""
         from . import disc_graph
         pd, sv_sr, st_sr, sv_gt, st_gt = self._d_state
         grads, _ = disc_graph.backward_features(self.D, pd, sv_sr, st_sr, True, False)
-        disc_graph.backward_features(self.D, pd, sv_gt, st_gt, True, False)
+        disc_graph.backward_features(self.D, pd, sv_gt, st_gt, True, False, defer_wgrad=defer_gt_wgrad)
         for n, p in self.D.named_parameters():
             p.grad = grads[n]
 
@@ -518,7 +520,8 @@ class TrainEngine:
             ops.debug_stamp(3)
             self._d_fwd_cls(early_gt)           # streams, as _d_two_stream does on its own) crashed hipStreamEndCapture (ROCm 7.2)
             ops.debug_stamp(4)
-            self._d_features()
+            deferred = [] if cfg.KERNEL.DEFER_D_WGRAD else None
+            self._d_features(deferred)
             ops.debug_stamp(5)
         ops.debug_stamp(6)
         with torch.autograd.set_multithreading_enabled(False):      # backward on this thread: one thread feeds the open capture
@@ -527,6 +530,18 @@ class TrainEngine:
         self.loss_values = vals
         self.g_opt.step()
         ops.debug_stamp(8)
+        # The side branch is the longer one (D(gt) forward + two backward passes against one generator backward).  The conv weight
+        # gradients of its last pass are leaves of that chain: they run HERE, on the generator's stream, which would otherwise idle
+        # until the join - each behind the event of its dy.  Same kernels, same arguments, same accumulation order per parameter
+        # (the D(sr) pass wrote its gradients before the D(gt) pass produced its first dy).
+        capturing = torch.cuda.is_current_stream_capturing()
+        for ev, launch, tensors in (deferred or ()):
+            main.wait_event(ev)
+            if not capturing:            # eager: the side stream's allocator must not hand these blocks out again before `main` is done
+                for t in tensors:        # with them.  Under capture nothing is handed out again inside the graph (the closures hold the
+                    if t is not None:    # tensors until every launch of the iteration is issued) - and recording the CAPTURE stream, which
+                        t.record_stream(main)   # is destroyed after the capture, left the allocator with a dangling stream (segfaults in later replays)
+            launch()
         main.wait_stream(self._side_d)
         self._d_step()
         ops.debug_stamp(9)

@@ -375,6 +375,44 @@ def test_conv_band_kernel(ops, case, monkeypatch):
     assert rel_err(nchw(out_b.cpu()), oref) < TOL
 
 
+@pytest.mark.parametrize("case", [(3, 32, 48, 64, 64, "2, 8"), (2, 24, 24, 128, 96, "2, 6"), (5, 12, 12, 96, 160, "2, 6"), (16, 12, 12, 512, 512, "2, 6"),
+                                  (1, 4, 16, 32, 32, "2, 8"), (2, 96, 96, 64, 64, "2, 8")])
+def test_conv_wgrad_stride2_all_taps_kernel(ops, case, monkeypatch):
+    """The stride-2 all-taps weight-gradient kernel (conv_wgrad_s2_kernel: 32 x 32 block x 9 taps per workgroup, waves split the
+    pixel tiles; tile shapes 2x8 / 2x6) against fp64 autograd and against the per-tap kernel (SST_WGRAD_S2=0): with the
+    producer's BatchNorm affine + LeakyReLU applied to the input and without, writing and accumulating."""
+    from srganst import _abi
+    B, H, W, Cin, Cout, tile = case
+    g = torch.Generator().manual_seed(83)
+    name = _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, Cin, Cout, 3, 2, 1).decode()
+    assert name == f"conv_wgrad_s2_kernel<{tile}, 8>", name
+    x = torch.randn(B, Cin, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    dy = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
+    for affine in (True, False):
+        w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        xin = F.leaky_relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2) if affine else x.double()
+        F.conv2d(xin, w, None, 2, 1).backward(dy.double())
+        kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), in_slope_const=0.2, in_act=ops.ACT_SLOPE) if affine else {}
+        dw = torch.full((Cout, Cin, 3, 3), 7.0).cuda()
+        ops.conv_wgrad(xd, dyd, dw, 3, 2, **kw)
+        assert rel_err(dw.cpu(), w.grad) < TOL
+        ops.conv_wgrad(xd, dyd, dw, 3, 2, accumulate=True, **kw)
+        assert rel_err(dw.cpu(), 2 * w.grad) < TOL
+        monkeypatch.setenv("SST_WGRAD_S2", "0")
+        assert "s2" not in _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, Cin, Cout, 3, 2, 1).decode()
+        dw_old = torch.empty_like(dw)
+        ops.conv_wgrad(xd, dyd, dw_old, 3, 2, **kw)
+        monkeypatch.delenv("SST_WGRAD_S2")
+        assert rel_err(dw_old.cpu(), w.grad) < TOL
+        dw2 = torch.empty_like(dw)
+        ops.conv_wgrad(xd, dyd, dw2, 3, 2, **kw)
+        dw3 = torch.empty_like(dw)
+        ops.conv_wgrad(xd, dyd, dw3, 3, 2, **kw)
+        assert torch.equal(dw2, dw3)                      # fixed-order sums: reproducible
+
+
 @pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 48, 48, 64, 128), (3, 12, 12, 128, 64), (1, 9, 16, 64, 64), (2, 6, 8, 64, 64),
                                   (16, 24, 24, 64, 64)])
 def test_conv_wgrad_band_kernel(ops, case, monkeypatch):
