@@ -621,9 +621,9 @@ struct WgS2Args {
 
 // S2_NW waves per workgroup: 8 = two per SIMD, one stages while the other multiplies (256 registers each); 4 = one per SIMD with
 // 512 registers (room for the scheduler to read LDS operands ahead)
-template <int TH, int TW, int S2_NW>
+template <int S, int TH, int TW, int S2_NW>
 struct WgS2Geom {
-  static constexpr int NPIX = TH * TW, PH = 2 * TH + 1, PW = 2 * TW + 1, NPX = PH * PW;
+  static constexpr int NPIX = TH * TW, PH = S * (TH - 1) + 3, PW = S * (TW - 1) + 3, NPX = PH * PW;
   static constexpr int XQ = (NPX * 8 + 63) / 64;           // 16-B quads per lane: X patch (8 quads = 32 channels per pixel)
   static constexpr int DQ = (NPIX * 8 + 63) / 64;          //                       dY tile
   static constexpr int WAVE_FLOATS = (XQ * 8 + DQ * 8) * 32;    // one wave's private region: [patch pixel slot][32 ci] then [tile pixel slot][32 co]
@@ -632,9 +632,9 @@ struct WgS2Geom {
   static_assert((size_t)2 * S2_NW * 32 * 33 * sizeof(float) <= LDS_BYTES, "exchange scratch (double-buffered) fits the staging area");
 };
 
-template <int TH, int TW, int S2_NW>
-__global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_s2_kernel(WgS2Args a) {
-  using G = WgS2Geom<TH, TW, S2_NW>;
+template <int S, int TH, int TW, int S2_NW>
+__global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_tile_kernel(WgS2Args a) {
+  using G = WgS2Geom<S, TH, TW, S2_NW>;
   constexpr int NPIX = G::NPIX, PW = G::PW, NPX = G::NPX, XQ = G::XQ, DQ = G::DQ;
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -667,7 +667,8 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_s2_kernel(WgS2Args a
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
     // origin of the patch (EDGE: may lie one row / one column outside the image: those quads are masked), < 2^31 floats (host check)
-    const int xo = ((b * a.H + 2 * oy0 - 1) * a.W + 2 * ox0 - 1) * a.Cin + ci0 + q4;
+    const int xo = ((b * a.H + S * oy0 - 1) * a.W + S * ox0 - 1) * a.Cin + ci0 + q4;
+    const bool last_y = oy0 + TH == a.Ho, last_x = ox0 + TW == a.Wo;
     const float* db = a.dy + ((size_t)(b * a.Ho + oy0) * a.Wo + ox0) * a.Cout + co0 + q4;
     okm = 0;
 #pragma unroll
@@ -675,7 +676,8 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_s2_kernel(WgS2Args a
       const int p = (lane >> 3) + 8 * u;
       const int pr = p / PW, pc = p - pr * PW;
       bool ok = 8 * u + 7 < NPX || p < NPX;              // slots past the patch exist in the last quad only (compile-time for the others)
-      if (EDGE) ok = ok && (pr > 0 || oy0 > 0) && (pc > 0 || ox0 > 0);           // bottom / right never leave the image (H, W even)
+      if (EDGE) ok = ok && (pr > 0 || oy0 > 0) && (pc > 0 || ox0 > 0);           // stride 2: bottom / right never leave the image (H, W even)
+      if (EDGE && S == 1) ok = ok && (pr < G::PH - 1 || !last_y) && (pc < PW - 1 || !last_x);
       const int off = xo + (pr * a.W + pc) * a.Cin;
       xr[u] = *reinterpret_cast<const f32x4*>(a.x + ((EDGE || 8 * u + 7 >= NPX) ? (ok ? off : ci0 + q4) : off));
       if (EDGE) okm |= ok ? (1u << u) : 0u;
@@ -688,8 +690,10 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_s2_kernel(WgS2Args a
     }
   };
   auto is_edge = [&](int t) {
-    const int rem = t % a.tiles_img;
-    return rem < a.tiles_x || rem % a.tiles_x == 0;
+    const int rem = t % a.tiles_img, tx = rem % a.tiles_x;
+    bool e = rem < a.tiles_x || tx == 0;
+    if (S == 1) e = e || rem >= a.tiles_img - a.tiles_x || tx == a.tiles_x - 1;
+    return e;
   };
   auto issue_any = [&](int t) {
     edge = is_edge(t);
@@ -728,9 +732,9 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_s2_kernel(WgS2Args a
 
   int t = t0 + wave;
   if (t < t1 && !(a.dbg & 2)) issue_any(t);
-  // per-lane fragment bases: lane (li = m or n, lh = k): dY pixel 2*ks + lh, X patch pixel const(ks, tap) + 2*lh
+  // per-lane fragment bases: lane (li = m or n, lh = k): dY pixel 2*ks + lh, X patch pixel const(ks, tap) + S*lh
   const float* const dl = ds + lh * 32 + li;
-  const float* const xl = xs + 2 * lh * 32 + li;
+  const float* const xl = xs + S * lh * 32 + li;
   for (; t < t1; t += S2_NW) {
     // (the previous tile's MFMA loop has issued all its LDS reads: LDS ops of a wave complete in order)
     if (!(a.dbg & 1)) {
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_s2_kernel(WgS2Args a
       const int py = (2 * ks) / TW, px = (2 * ks) % TW;
       a_ = dl[2 * ks * 32];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) b_[tap] = xl[((2 * py + tap / 3) * PW + 2 * px + tap % 3) * 32];
+      for (int tap = 0; tap < 9; ++tap) b_[tap] = xl[((S * py + tap / 3) * PW + S * px + tap % 3) * 32];
     };
     fetch(0, av, bv);
     __builtin_amdgcn_sched_barrier(0);
@@ -799,40 +803,50 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_s2_kernel(WgS2Args a
 struct WgS2Plan { int th, tw, nw, nchunk, tpc, ntiles; };
 inline WgS2Plan wgrad_s2_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
   WgS2Plan pl{0, 0, 0, 0, 0, 0};
-  if (ksize != 3 || stride != 2 || ((H | W) & 1) || (Cin & 31) || (Cout & 31) || B <= 0) return pl;
-  if (const char* e = getenv("SST_WGRAD_S2")) {
+  if (ksize != 3 || (stride != 1 && stride != 2) || (Cin & 31) || (Cout & 31) || B <= 0) return pl;
+  if (stride == 2 && ((H | W) & 1)) return pl;
+  bool force = false;                                   // SST_WGRAD_S2 / SST_WGRAD_S1T: 0 = off, 1 = also below the work threshold (tests)
+  if (const char* e = getenv(stride == 2 ? "SST_WGRAD_S2" : "SST_WGRAD_S1T")) {
     if (atoi(e) == 0) return pl;
+    force = true;
   }
-  const int Ho = H / 2, Wo = W / 2;
-  int th = 0, tw = 0, S2_NW = 8;
-  if (const char* e = getenv("SST_WGRAD_S2_NW")) S2_NW = atoi(e) == 4 ? 4 : 8;        // dev
-  if (Wo % 8 == 0 && Ho % 2 == 0) { th = 2; tw = 8; }
-  else if (Wo % 6 == 0 && Ho % 2 == 0) { th = 2; tw = 6; }
-  if (S2_NW == 4 && th && Ho % 4 == 0) th = 4;
+  const int Ho = H / stride, Wo = W / stride;
+  constexpr int NW = 8;
+  int th = 0, tw = 0;
+  if (stride == 2) {
+    if (Wo % 8 == 0 && Ho % 2 == 0) { th = 2; tw = 8; }
+    else if (Wo % 6 == 0 && Ho % 2 == 0) { th = 2; tw = 6; }
+  } else {
+    // stride 1 (same kernel, 4-row tiles: a 6 x 10 patch per 32 pixels): single layers with enough work only - the trunk's grouped
+    // launches and small layers stay where they are (conv_wgrad_band_kernel / per-tap kernel)
+    if (2.0 * B * H * W * Cin * Cout * 9 < 2.5e9 && !force) return pl;
+    if (Wo % 8 == 0 && Ho % 4 == 0) { th = 4; tw = 8; }
+    else if (Wo % 6 == 0 && Ho % 4 == 0) { th = 4; tw = 6; }
+  }
   if (!th || (int64_t)B * H * W * Cin >= (1ll << 31)) return pl;
   const int ntiles = B * (Ho / th) * (Wo / tw);
   const int nblk = (Cout >> 5) * (Cin >> 5);
   // ~one workgroup (8 waves) per CU; a chunk is a multiple of 8 tiles (the waves split it), never less than 8
   int nchunk = 256 / nblk;
   if (nchunk < 1) nchunk = 1;
-  int tpc = ((ntiles + nchunk - 1) / nchunk + S2_NW - 1) / S2_NW * S2_NW;
-  if (tpc < S2_NW) tpc = S2_NW;
+  int tpc = ((ntiles + nchunk - 1) / nchunk + NW - 1) / NW * NW;
+  if (tpc < NW) tpc = NW;
   nchunk = (ntiles + tpc - 1) / tpc;
-  pl = WgS2Plan{th, tw, S2_NW, nchunk, tpc, ntiles};
+  pl = WgS2Plan{th, tw, NW, nchunk, tpc, ntiles};
   return pl;
 }
 
-template <int TH, int TW, int S2_NW>
+template <int S, int TH, int TW, int S2_NW>
 static int launch_wgrad_s2_t(const WgS2Args& a, const WgS2Plan& pl, hipStream_t st) {
-  using G = WgS2Geom<TH, TW, S2_NW>;
+  using G = WgS2Geom<S, TH, TW, S2_NW>;
   static bool lds_ok = false;
   if (!lds_ok) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_s2_kernel<TH, TW, S2_NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)G::LDS_BYTES) != hipSuccess)
-      return sst_set_error(SST_ERR_HIP, "conv_wgrad_s2: cannot raise the LDS limit");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tile_kernel<S, TH, TW, S2_NW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)
+      return sst_set_error(SST_ERR_HIP, "conv_wgrad_tile: cannot raise the LDS limit");
     lds_ok = true;
   }
-  conv_wgrad_s2_kernel<TH, TW, S2_NW><<<dim3(pl.nchunk, (a.Cout >> 5) * (a.Cin >> 5)), S2_NW * 64, G::LDS_BYTES, st>>>(a);
+  conv_wgrad_tile_kernel<S, TH, TW, S2_NW><<<dim3(pl.nchunk, (a.Cout >> 5) * (a.Cin >> 5)), S2_NW * 64, G::LDS_BYTES, st>>>(a);
   return SST_OK;
 }
 
@@ -864,12 +878,12 @@ static int launch_wgrad_band(WgradArgs& a, const WgBandPlan& pl, int njobs, hipS
 // Chunk count (slab floats per layer = chunks*k*k*Cout*Cin) that sst_conv_wgrad (njobs = 1) / sst_conv_wgrad_grouped use
 // for this shape; H, W are the INPUT size.
 SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
-  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
-  if (pl.R) return pl.nchunk;
   if (njobs == 1) {
     const WgS2Plan p2 = wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride);
     if (p2.th) return p2.nchunk;
   }
+  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
+  if (pl.R) return pl.nchunk;
   const int pad = ksize / 2;
   if (Cin == 3 && ksize == 3 && stride == 1) {         // 3-channel-input kernel (one chunk per band) or the general one
     const int a = B * ((H + C3_ROWS - 1) / C3_ROWS), g = sst_conv_wgrad_chunks(B, H, W, Cin, Cout, ksize);
@@ -880,16 +894,16 @@ SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int k
 
 // Name of the main kernel sst_conv_wgrad (njobs = 1) / sst_conv_wgrad_grouped launch for this shape (rocprofv3 spelling).
 SST_API const char* sst_conv_wgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
-  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
-  if (pl.R) return ((pl.R + 2) * (W + 2) * 16 + CONV_NT - 1) / CONV_NT <= 7 ? "conv_wgrad_band_kernel<7>" : "conv_wgrad_band_kernel<10>";
   if (njobs == 1) {
     const WgS2Plan p2 = wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride);
     if (p2.th) {
-      static thread_local char nm[48];
-      snprintf(nm, sizeof(nm), "conv_wgrad_s2_kernel<%d, %d, %d>", p2.th, p2.tw, p2.nw);
+      static thread_local char nm[56];
+      snprintf(nm, sizeof(nm), "conv_wgrad_tile_kernel<%d, %d, %d, %d>", stride, p2.th, p2.tw, p2.nw);
       return nm;
     }
   }
+  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
+  if (pl.R) return ((pl.R + 2) * (W + 2) * 16 + CONV_NT - 1) / CONV_NT <= 7 ? "conv_wgrad_band_kernel<7>" : "conv_wgrad_band_kernel<10>";
   if (Cin == 3 && ksize == 3 && stride == 1) return "wgrad_k3c3_kernel";
   return ((Cin & 3) == 0 && (Cout & 3) == 0) ? "conv_wgrad_kernel<true>" : "conv_wgrad_kernel<false>";
 }
@@ -918,8 +932,8 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   }
   const int KK = ksize * ksize;
   dim3 grid(nchunk, KK, ((Cout + 63) / 64) * ((Cin + 63) / 64));
-  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, 1);
-  const WgS2Plan p2 = pl.R ? WgS2Plan{0, 0, 0, 0, 0} : wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride);
+  const WgS2Plan p2 = wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride);
+  const WgBandPlan pl = p2.th ? WgBandPlan{0, 0, 0, 0, 0} : wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, 1);
   if (pl.R) {
     const int rc = launch_wgrad_band(a, pl, 1, sst_stream(stream), no_tab);
     if (rc != SST_OK) return rc;
@@ -932,9 +946,8 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
     s2.dbg = getenv("SST_WGRAD_S2_DBG") ? atoi(getenv("SST_WGRAD_S2_DBG")) : 0;
     s2.tiles_x = a.Wo / p2.tw; s2.tiles_img = (a.Ho / p2.th) * s2.tiles_x; s2.ntiles = p2.ntiles; s2.tpc = p2.tpc;
     int rc;
-    if (p2.nw == 8) rc = p2.tw == 8 ? launch_wgrad_s2_t<2, 8, 8>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<2, 6, 8>(s2, p2, sst_stream(stream));
-    else if (p2.th == 4) rc = p2.tw == 8 ? launch_wgrad_s2_t<4, 8, 4>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<4, 6, 4>(s2, p2, sst_stream(stream));
-    else rc = p2.tw == 8 ? launch_wgrad_s2_t<2, 8, 4>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<2, 6, 4>(s2, p2, sst_stream(stream));
+    if (stride == 2) rc = p2.tw == 8 ? launch_wgrad_s2_t<2, 2, 8, 8>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<2, 2, 6, 8>(s2, p2, sst_stream(stream));
+    else rc = p2.tw == 8 ? launch_wgrad_s2_t<1, 4, 8, 8>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<1, 4, 6, 8>(s2, p2, sst_stream(stream));
     if (rc != SST_OK) return rc;
     nchunk = p2.nchunk;
   } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && !getenv("SST_WGRAD_NO_K3C3")) {

@@ -375,42 +375,53 @@ def test_conv_band_kernel(ops, case, monkeypatch):
     assert rel_err(nchw(out_b.cpu()), oref) < TOL
 
 
-@pytest.mark.parametrize("case", [(3, 32, 48, 64, 64, "2, 8"), (2, 24, 24, 128, 96, "2, 6"), (5, 12, 12, 96, 160, "2, 6"), (16, 12, 12, 512, 512, "2, 6"),
-                                  (1, 4, 16, 32, 32, "2, 8"), (2, 96, 96, 64, 64, "2, 8")])
-def test_conv_wgrad_stride2_all_taps_kernel(ops, case, monkeypatch):
-    """The stride-2 all-taps weight-gradient kernel (conv_wgrad_s2_kernel: 32 x 32 block x 9 taps per workgroup, waves split the
-    pixel tiles; tile shapes 2x8 / 2x6) against fp64 autograd and against the per-tap kernel (SST_WGRAD_S2=0): with the
-    producer's BatchNorm affine + LeakyReLU applied to the input and without, writing and accumulating."""
+@pytest.mark.parametrize("case", [(3, 32, 48, 64, 64, 2, "2, 8"), (2, 24, 24, 128, 96, 2, "2, 6"), (5, 12, 12, 96, 160, 2, "2, 6"),
+                                  (16, 12, 12, 512, 512, 2, "2, 6"), (1, 4, 16, 32, 32, 2, "2, 8"), (2, 96, 96, 64, 64, 2, "2, 8"),
+                                  (2, 8, 16, 32, 32, 1, "4, 8"), (3, 16, 24, 64, 96, 1, "4, 8"), (2, 12, 12, 64, 32, 1, "4, 6"),
+                                  (16, 12, 12, 256, 512, 1, "4, 6"), (1, 4, 8, 32, 64, 1, "4, 8"), (2, 48, 48, 64, 128, 1, "4, 8")])
+def test_conv_wgrad_all_taps_tile_kernel(ops, case, monkeypatch):
+    """The all-taps weight-gradient kernel for single layers (conv_wgrad_tile_kernel: 32 x 32 block x 9 taps per workgroup, its 8
+    waves split the pixel tiles; stride 2 with 2x8 / 2x6 tiles, stride 1 with 4x8 / 4x6 tiles) against fp64 autograd and against
+    the kernels it replaces (SST_WGRAD_S2=0 / SST_WGRAD_S1T=0): with the producer's BatchNorm affine + LeakyReLU applied to the input
+    and without, writing and accumulating, interior and edge tiles."""
     from srganst import _abi
-    B, H, W, Cin, Cout, tile = case
+    B, H, W, Cin, Cout, stride, tile = case
+    env = "SST_WGRAD_S2" if stride == 2 else "SST_WGRAD_S1T"
+    monkeypatch.setenv(env, "1")                          # also below the work threshold of the automatic choice
     g = torch.Generator().manual_seed(83)
-    name = _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, Cin, Cout, 3, 2, 1).decode()
-    assert name == f"conv_wgrad_s2_kernel<{tile}, 8>", name
+    name = _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, Cin, Cout, 3, stride, 1).decode()
+    assert name == f"conv_wgrad_tile_kernel<{stride}, {tile}, 8>", name
     x = torch.randn(B, Cin, H, W, generator=g)
     sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
-    dy = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    dy = torch.randn(B, Cout, H // stride, W // stride, generator=g)
     xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
     for affine in (True, False):
         w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
         xin = F.leaky_relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.2) if affine else x.double()
-        F.conv2d(xin, w, None, 2, 1).backward(dy.double())
+        F.conv2d(xin, w, None, stride, 1).backward(dy.double())
         kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), in_slope_const=0.2, in_act=ops.ACT_SLOPE) if affine else {}
         dw = torch.full((Cout, Cin, 3, 3), 7.0).cuda()
-        ops.conv_wgrad(xd, dyd, dw, 3, 2, **kw)
+        ops.conv_wgrad(xd, dyd, dw, 3, stride, **kw)
         assert rel_err(dw.cpu(), w.grad) < TOL
-        ops.conv_wgrad(xd, dyd, dw, 3, 2, accumulate=True, **kw)
+        ops.conv_wgrad(xd, dyd, dw, 3, stride, accumulate=True, **kw)
         assert rel_err(dw.cpu(), 2 * w.grad) < TOL
-        monkeypatch.setenv("SST_WGRAD_S2", "0")
-        assert "s2" not in _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, Cin, Cout, 3, 2, 1).decode()
+        monkeypatch.setenv(env, "0")
+        assert "tile" not in _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, Cin, Cout, 3, stride, 1).decode()
         dw_old = torch.empty_like(dw)
-        ops.conv_wgrad(xd, dyd, dw_old, 3, 2, **kw)
-        monkeypatch.delenv("SST_WGRAD_S2")
+        ops.conv_wgrad(xd, dyd, dw_old, 3, stride, **kw)
+        monkeypatch.setenv(env, "1")
         assert rel_err(dw_old.cpu(), w.grad) < TOL
         dw2 = torch.empty_like(dw)
-        ops.conv_wgrad(xd, dyd, dw2, 3, 2, **kw)
+        ops.conv_wgrad(xd, dyd, dw2, 3, stride, **kw)
         dw3 = torch.empty_like(dw)
-        ops.conv_wgrad(xd, dyd, dw3, 3, 2, **kw)
+        ops.conv_wgrad(xd, dyd, dw3, 3, stride, **kw)
         assert torch.equal(dw2, dw3)                      # fixed-order sums: reproducible
+    # a PReLU-style slope outside [0, 1] takes the select form of the activation
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(torch.where(x.double() > 0, x.double(), -1.5 * x.double()), w, None, stride, 1).backward(dy.double())
+    dw = torch.empty(Cout, Cin, 3, 3).cuda()
+    ops.conv_wgrad(xd, dyd, dw, 3, stride, in_slope_const=-1.5, in_act=ops.ACT_SLOPE)
+    assert rel_err(dw.cpu(), w.grad) < TOL
 
 
 @pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 48, 48, 64, 128), (3, 12, 12, 128, 64), (1, 9, 16, 64, 64), (2, 6, 8, 64, 64),
