@@ -444,6 +444,113 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_kernel(const float* __rest
     }
   }
 }
+// ---- the same layer on the matrix cores (round 2): M = 32 output channels x 2 halves, N = (ky, kx, ci) = 27 of 32 columns, K = pixels.
+// No im2col: lane n of the B operand always wants the SAME (ky, kx, ci) of the pixel's 3x3x3 window, i.e. a fixed offset into the
+// raw 3-channel patch [3 rows][34 px x 3 ch] in LDS (+ 3 floats for the second pixel of the K pair); lanes 27..31 read a zero
+// region.  The A operand (dY) is loaded straight from global memory in MFMA layout (lane = (channel, pixel of the pair): two 128-B
+// segments per load).  One wave = one 32-pixel row segment (16 K steps x 2 MFMAs), 4 waves per workgroup summed through LDS, one
+// 64 x 27 partial per workgroup; plenty of resident waves instead of software pipelining - the launch is bound by streaming dY
+// (37.7 MB at B = 16 / 96 px) once.  Needs W % 32 == 0 and Cout == 64 (Discriminator.features[0] at 96 and 192 px); other shapes
+// keep the VALU kernel above.
+constexpr int C3M_ROW = 104;                 // floats per patch row in LDS (34 px x 3 ch = 102, padded)
+constexpr int C3M_WAVE = 3 * C3M_ROW + 96;   // + the zero region the idle columns read (16 K steps x 6 floats)
+__global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ slab, int B, int H, int W, int ntiles) {
+  __shared__ float patch[4 * C3M_WAVE];
+  __shared__ float scr[4 * 32 * 33];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  constexpr int Cout = 64;
+  float* const ps = patch + wave * C3M_WAVE;
+  const int t = blockIdx.x * 4 + wave;
+  const bool live = t < ntiles;
+  const int tpr = W >> 5;                                 // tiles per image row
+  const int b = t / (H * tpr), rem = t - b * (H * tpr);
+  const int y = rem / tpr, x0 = (rem - y * tpr) << 5;
+  // dY in MFMA layout: K step ks, half h -> channel 32h + li of pixel x0 + 2ks + lh
+  float av[16][2];
+  {
+    const float* dp = dy + (((size_t)b * H + y) * W + x0 + lh) * Cout + li;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      av[ks][0] = live ? dp[(size_t)(2 * ks) * Cout] : 0.f;
+      av[ks][1] = live ? dp[(size_t)(2 * ks) * Cout + 32] : 0.f;
+    }
+  }
+  // X patch rows y-1 .. y+1, columns x0-1 .. x0+32 (as floats: (x0-1)*3 .. +102), zero outside the image; then the zero region
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int i = lane + 64 * u;
+    if (i < 306) {
+      const int r = i / 102, c = i - r * 102;
+      const int iy = y - 1 + r, fx = (x0 - 1) * 3 + c;
+      const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)fx < (unsigned)(W * 3);
+      ps[r * C3M_ROW + c] = ok ? x[((size_t)b * H + iy) * W * 3 + fx] : 0.f;
+    }
+  }
+  for (int i = lane; i < 96; i += 64) ps[3 * C3M_ROW + i] = 0.f;
+  // this lane's column n = li = ky*9 + kx*3 + ci  ->  fixed offset into the patch (+ 3 floats for the pair's second pixel)
+  const int ky = li / 9, kr = li - ky * 9;
+  const float* const bl = ps + (li < 27 ? ky * C3M_ROW + kr + 3 * lh : 3 * C3M_ROW);
+  f32x16 acc[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const float bv = bl[6 * ks];                          // LDS ops of a wave complete in order: the stores above have landed
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][0], bv, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][1], bv, acc[1], 0, 0, 0);
+  }
+  // 4 waves -> one 64 x 27 partial (fixed order), slab [chunk][tap][Cout][3]
+  float* const out = slab + (size_t)blockIdx.x * 9 * Cout * 3;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[h][r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 8 * wave + 4 * lh + j;
+      const float v = ((scr[row * 33 + li] + scr[(32 + row) * 33 + li]) + scr[(64 + row) * 33 + li]) + scr[(96 + row) * 33 + li];
+      if (li < 27) out[((size_t)(li / 3) * Cout + 32 * h + row) * 3 + li % 3] = v;
+    }
+  }
+}
+// dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci] for the kernel above (64 x 27 outputs, > 1000 chunks): one workgroup per 64
+// outputs, 16 chunk groups of 64 lanes (coalesced 256-B rows, 8 loads in flight per thread), combined in fixed order through LDS.
+__global__ __launch_bounds__(1024) void c3m_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunk,
+                                                          int accumulate) {
+  __shared__ float part[16][64];
+  constexpr int TOTAL = 9 * 64 * 3;
+  const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float t = 0.f;
+  int c = gq;
+  for (; c + 7 * 16 < nchunk; c += 8 * 16) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(c + 16 * u) * TOTAL + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  for (; c < nchunk; c += 16) t += slab[(size_t)c * TOTAL + i];
+  part[gq][o] = t;
+  __syncthreads();
+  if (gq == 0) {
+    t = part[0][o];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][o];
+    const int tap = i / 192, oc = i - tap * 192;         // slab order [tap][co][ci] -> dW[co][ci][tap]
+    float* d = dw + (size_t)oc * 9 + tap;
+    *d = accumulate ? *d + t : t;
+  }
+}
+inline bool k3c3_mfma_applies(int W, int Cout) { return (W & 31) == 0 && Cout == 64 && !getenv("SST_WGRAD_NO_K3C3_MFMA"); }
+inline int k3c3_mfma_chunks(int B, int H, int W) { return (B * H * (W >> 5) + 3) / 4; }
+
 inline bool k3c3_applies(int Cin, int ksize, int stride, const float* in_scale, int in_act) {
   return Cin == 3 && ksize == 3 && stride == 1 && !in_scale && in_act == ACT_NONE;
 }
@@ -885,8 +992,10 @@ SST_API int sst_conv_wgrad_chunks2(int B, int H, int W, int Cin, int Cout, int k
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
   if (pl.R) return pl.nchunk;
   const int pad = ksize / 2;
-  if (Cin == 3 && ksize == 3 && stride == 1) {         // 3-channel-input kernel (one chunk per band) or the general one
-    const int a = B * ((H + C3_ROWS - 1) / C3_ROWS), g = sst_conv_wgrad_chunks(B, H, W, Cin, Cout, ksize);
+  if (Cin == 3 && ksize == 3 && stride == 1) {         // 3-channel-input kernels (one chunk per workgroup) or the general one
+    int a = B * ((H + C3_ROWS - 1) / C3_ROWS);
+    const int g = sst_conv_wgrad_chunks(B, H, W, Cin, Cout, ksize);
+    if (k3c3_mfma_applies(W, Cout) && k3c3_mfma_chunks(B, H, W) > a) a = k3c3_mfma_chunks(B, H, W);
     return a > g ? a : g;
   }
   return sst_conv_wgrad_chunks(B, (H + 2 * pad - ksize) / stride + 1, (W + 2 * pad - ksize) / stride + 1, Cin, Cout, ksize);
@@ -904,7 +1013,7 @@ SST_API const char* sst_conv_wgrad_kernel_name(int B, int H, int W, int Cin, int
   }
   const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, njobs);
   if (pl.R) return ((pl.R + 2) * (W + 2) * 16 + CONV_NT - 1) / CONV_NT <= 7 ? "conv_wgrad_band_kernel<7>" : "conv_wgrad_band_kernel<10>";
-  if (Cin == 3 && ksize == 3 && stride == 1) return "wgrad_k3c3_kernel";
+  if (Cin == 3 && ksize == 3 && stride == 1) return k3c3_mfma_applies(W, Cout) ? "wgrad_k3c3_mfma_kernel" : "wgrad_k3c3_kernel";
   return ((Cin & 3) == 0 && (Cout & 3) == 0) ? "conv_wgrad_kernel<true>" : "conv_wgrad_kernel<false>";
 }
 
@@ -950,6 +1059,13 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
     else rc = p2.tw == 8 ? launch_wgrad_s2_t<1, 4, 8, 8>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<1, 4, 6, 8>(s2, p2, sst_stream(stream));
     if (rc != SST_OK) return rc;
     nchunk = p2.nchunk;
+  } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && k3c3_mfma_applies(W, Cout)) {
+    nchunk = k3c3_mfma_chunks(B, H, W);
+    wgrad_k3c3_mfma_kernel<<<nchunk, CONV_NT, 0, sst_stream(stream)>>>(x, dy, slab, B, H, W, B * H * (W >> 5));
+    SST_LAUNCH_CHECK("wgrad_k3c3_mfma_kernel");
+    c3m_reduce_kernel<<<27, 1024, 0, sst_stream(stream)>>>(slab, dw, nchunk, accumulate);
+    SST_LAUNCH_CHECK("c3m_reduce_kernel");
+    return SST_OK;
   } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && !getenv("SST_WGRAD_NO_K3C3")) {
     nchunk = B * ((H + C3_ROWS - 1) / C3_ROWS);
     const size_t lds = (size_t)(C3_ROWS + 2) * ((W + 2) * 3 + 3) * sizeof(float);

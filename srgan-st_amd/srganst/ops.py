@@ -283,7 +283,10 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
             int(in_act), B, H, W, cin, cout, stride, ksize, int(accumulate))
     check(_abi.lib().sst_conv_wgrad(*args, stream_ptr()), "sst_conv_wgrad")
     flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
-    name = (_wgrad_name(B, H, W, cin, cout, ksize, stride, 1) + "+wgrad_reduce_kernel") if (PROFILE is not None or TRACE is not None) else ""
+    name = ""
+    if PROFILE is not None or TRACE is not None:
+        name = _wgrad_name(B, H, W, cin, cout, ksize, stride, 1)
+        name += "+c3m_reduce_kernel" if name == "wgrad_k3c3_mfma_kernel" else "+wgrad_reduce_kernel"
     _prof_end(e0, name, flops)
     _trace(name, flops, lambda: _abi.lib().sst_conv_wgrad(*args, stream_ptr()),
            x, dy, slab, dw_out, in_scale, in_shift, in_slope)

@@ -424,6 +424,37 @@ def test_conv_wgrad_all_taps_tile_kernel(ops, case, monkeypatch):
     assert rel_err(dw.cpu(), w.grad) < TOL
 
 
+@pytest.mark.parametrize("case", [(2, 8, 32, 64), (3, 5, 64, 64), (1, 1, 32, 64), (16, 96, 96, 64), (2, 12, 96, 64)])
+def test_conv_wgrad_3_channel_input_mfma_kernel(ops, case, monkeypatch):
+    """Weight gradient of the discriminator's first layer (3 input channels, reference model.py:32) on the matrix cores
+    (wgrad_k3c3_mfma_kernel: N = (ky, kx, ci) = 27 of 32 columns read straight from the raw patch) against fp64 autograd and against
+    the VALU kernel it replaces, writing and accumulating; image borders on all four sides, partial last workgroup."""
+    from srganst import _abi
+    B, H, W, Cout = case
+    assert _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, 3, Cout, 3, 1, 1).decode() == "wgrad_k3c3_mfma_kernel"
+    g = torch.Generator().manual_seed(85)
+    x = torch.randn(B, 3, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(dy.double())
+    xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
+    dw = torch.full((Cout, 3, 3, 3), 7.0).cuda()
+    ops.conv_wgrad(xd, dyd, dw, 3, 1)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+    ops.conv_wgrad(xd, dyd, dw, 3, 1, accumulate=True)
+    assert rel_err(dw.cpu(), 2 * w.grad) < TOL
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(xd, dyd, dw2, 3, 1)
+    dw3 = torch.empty_like(dw)
+    ops.conv_wgrad(xd, dyd, dw3, 3, 1)
+    assert torch.equal(dw2, dw3)
+    monkeypatch.setenv("SST_WGRAD_NO_K3C3_MFMA", "1")
+    assert _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, 3, Cout, 3, 1, 1).decode() == "wgrad_k3c3_kernel"
+    dw_old = torch.empty_like(dw)
+    ops.conv_wgrad(xd, dyd, dw_old, 3, 1)
+    assert rel_err(dw_old.cpu(), w.grad) < TOL
+
+
 @pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 48, 48, 64, 128), (3, 12, 12, 128, 64), (1, 9, 16, 64, 64), (2, 6, 8, 64, 64),
                                   (16, 24, 24, 64, 64)])
 def test_conv_wgrad_band_kernel(ops, case, monkeypatch):
@@ -508,6 +539,7 @@ def test_conv_wgrad_three_channel_input(ops, case, monkeypatch):
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy.double())
     from srganst import _abi
+    monkeypatch.setenv("SST_WGRAD_NO_K3C3_MFMA", "1")     # the MFMA form of this layer has its own test
     assert _abi.lib().sst_conv_wgrad_kernel_name(B, H, W, 3, Cout, 3, 1, 1) == b"wgrad_k3c3_kernel"
     dw = torch.full((Cout, 3, 3, 3), 7.0).cuda()
     ops.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw, 3, 1)
