@@ -160,11 +160,12 @@ def backward_classifier(module, p, sv, dout, need_param_grads, st=None):
     return {"views": views, "acc": acc, "grads": grads, "g": g}
 
 
-def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=None):
+def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=None, defer_below=None):
     """Backward of the feature stack (model.py:30-59) of one pass, continuing from backward_classifier's state.
     defer_wgrad (a list): the conv weight gradients are not launched here - they are leaves of the backward chain (nothing in this
     pass reads them) - but appended as (event recorded on the current stream once dy exists, launch closure); the caller runs them
-    wherever the chip has room (engine.TrainEngine._iter_gd: on the generator's stream once its backward is done)."""
+    wherever the chip has room (engine.TrainEngine._iter_gd: on the generator's stream once its backward is done).  defer_below: only
+    the layers with index < defer_below (the ones the chain reaches last) are deferred."""
     views, acc, grads, g = st["views"], st["acc"], st["grads"], st["g"]
 
     def G(name):
@@ -201,7 +202,7 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
             def launch(r=r, dy=dy, dwc=dwc):
                 ops.conv_wgrad(r["x"], dy, dwc, 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
                                in_slope_const=LRELU, in_act=r["x_act"], accumulate=acc)
-            if defer_wgrad is not None:
+            if defer_wgrad is not None and (defer_below is None or li < defer_below):
                 ev = torch.cuda.Event()
                 ev.record()
                 defer_wgrad.append((ev, launch, (r["x"], dy, dwc, r["x_scale"], r["x_shift"])))

@@ -424,7 +424,8 @@ class TrainEngine:
         from . import disc_graph
         pd, sv_sr, st_sr, sv_gt, st_gt = self._d_state
         grads, _ = disc_graph.backward_features(self.D, pd, sv_sr, st_sr, True, False)
-        disc_graph.backward_features(self.D, pd, sv_gt, st_gt, True, False, defer_wgrad=defer_gt_wgrad)
+        disc_graph.backward_features(self.D, pd, sv_gt, st_gt, True, False, defer_wgrad=defer_gt_wgrad,
+                                     defer_below=int(self.config.KERNEL.DEFER_D_WGRAD))
         for n, p in self.D.named_parameters():
             p.grad = grads[n]
 

@@ -341,7 +341,7 @@ def test_train_engine_schedules_are_bit_identical(interval):
     def run(gd, two, use_graph, reuse=True, early=True, defer=True):
         cfg = make_cfg(16, 2, 8)
         cfg.KERNEL.OVERLAP_GD, cfg.KERNEL.D_TWO_STREAMS, cfg.KERNEL.REUSE_D_SR, cfg.KERNEL.EARLY_D_GT = gd, two, reuse, early
-        cfg.KERNEL.DEFER_D_WGRAD = defer
+        cfg.KERNEL.DEFER_D_WGRAD = {True: 8, False: 0}.get(defer, defer)      # layers whose last-pass weight gradients move to the other stream
         torch.manual_seed(1)
         D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
         cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
@@ -372,7 +372,7 @@ def test_train_engine_schedules_are_bit_identical(interval):
         for k in ref:
             assert torch.equal(ref[k], out[k]), (gd, two, use_graph, reuse, early, k)
     # ... and without moving the last pass's weight gradients to the generator's stream (KERNEL.DEFER_D_WGRAD)
-    for use_graph in (False, True):
-        out = run(True, False, use_graph, defer=False)
+    for use_graph, defer in ((False, False), (True, False), (True, 3)):
+        out = run(True, False, use_graph, defer=defer)
         for k in ref:
-            assert torch.equal(ref[k], out[k]), ("no defer", use_graph, k)
+            assert torch.equal(ref[k], out[k]), ("defer", defer, use_graph, k)
