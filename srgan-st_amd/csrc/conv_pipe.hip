@@ -171,7 +171,10 @@ __device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float v[4], int
   }
 }
 
-template <int S, int TW, int MODE>
+// MS: units of several stages (cb_per > 1) - the staging addresses of a tile are kept in registers and moved from one channel block
+// to the next; single-stage layers (64 input channels) get the instantiation without them (measured: the extra registers cost the
+// 96-px stride-2 layer 4 us).
+template <int S, int TW, int MODE, bool MS>
 __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_pipe_kernel(PipeArgs a) {
   using G = PipeGeom<S, TW, MODE>;
   constexpr int NACC = G::NACC, NPAIR = G::NPAIR;
@@ -226,25 +229,38 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
   f32x4 ssc, ssh;
   const float* sc_base = a.in_scale ? a.in_scale : a.x;          // no affine: two dummy (never used) loads keep the load count fixed
   const float* sh_base = a.in_scale ? a.in_shift : a.x;
-  auto stage_load = [&](const Stage& s) {
-    okmask = 0;
+  // same_tile (wave-uniform): the stage is the next 64-channel block of the tile just loaded - every address moves by one block and
+  // the padding mask stays; the per-quad address arithmetic (division, image-boundary wraps, bounds) is only redone for a new
+  // tile.  VALU work is not hidden behind the MFMAs on this chip: per stage it was 25 instructions per quad.
+  unsigned boffs[MS ? NU : 1];
+  auto stage_load = [&](const Stage& s, bool same_tile) {
+    if (MS && same_tile) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int p = p0 + 16 * u;
-      const int pr = p / PW, pc = p - pr * PW;
-      int rr = s.rem0 + pr, b = s.b0;
-#pragma unroll
-      for (int k = 0; k <= NB; ++k) {
-        const bool wrap = rr >= HV;
-        rr -= wrap ? HV : 0;
-        b += wrap ? 1 : 0;
+      for (int u = 0; u < NU; ++u) {
+        boffs[u] += CB * 4u;                                       // masked quads keep reading (in bounds) near the tensor's origin
+        PIPE_GLOAD(sv[u], boffs[u], a.x);
       }
-      const int iy = MODE ? rr : rr - 1, ix = s.ix0 + pc;        // MODE 0: virtual row 0 of an image is its (shared) zero row; MODE 1: row H is
-      const bool ok = p < NP && (MODE ? rr < a.H : rr >= 1) && b < a.B && (unsigned)ix < (unsigned)a.W;
-      const int off = ((b * a.H + iy) * a.W + ix) * a.Cin + s.c0 + c4;          // < 2^29 floats (host check)
-      const unsigned boff = (ok ? (unsigned)off : (unsigned)c4) * 4u;
-      PIPE_GLOAD(sv[u], boff, a.x);
-      okmask |= ok ? (1u << u) : 0u;
+    } else {
+      okmask = 0;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int p = p0 + 16 * u;
+        const int pr = p / PW, pc = p - pr * PW;
+        int rr = s.rem0 + pr, b = s.b0;
+#pragma unroll
+        for (int k = 0; k <= NB; ++k) {
+          const bool wrap = rr >= HV;
+          rr -= wrap ? HV : 0;
+          b += wrap ? 1 : 0;
+        }
+        const int iy = MODE ? rr : rr - 1, ix = s.ix0 + pc;      // MODE 0: virtual row 0 of an image is its (shared) zero row; MODE 1: row H is
+        const bool ok = p < NP && (MODE ? rr < a.H : rr >= 1) && b < a.B && (unsigned)ix < (unsigned)a.W;
+        const int off = ((b * a.H + iy) * a.W + ix) * a.Cin + s.c0 + c4;        // < 2^29 floats (host check)
+        const unsigned boff = (ok ? (unsigned)off : (unsigned)c4) * 4u;
+        if (MS) boffs[u] = boff;
+        PIPE_GLOAD(sv[u], boff, a.x);
+        okmask |= ok ? (1u << u) : 0u;
+      }
     }
     const unsigned coff = (unsigned)(a.in_scale ? s.c0 + c4 : c4) * 4u;
     PIPE_GLOAD(ssc, coff, sc_base);
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
   // prologue: first stage
 #pragma unroll
   for (int i = 0; i < PIPE_RING; ++i) PIPE_WCHUNK(ring[i], cur.w, i);
-  stage_load(cur);
+  stage_load(cur, false);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   stage_store();
@@ -349,7 +365,7 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
         for (int j = 0; j < 4; ++j) acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[ai], 0, 0, 0);
         if (i + PIPE_RING < 18) PIPE_WCHUNK(ring[i % PIPE_RING], cur.w, i + PIPE_RING);
         else PIPE_WCHUNK(ring[i % PIPE_RING], nxt.w, i + PIPE_RING - 18);
-        if (i == 0) stage_load(nxt);
+        if (i == 0) stage_load(nxt, !unit_end);
         av = an;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -508,7 +524,8 @@ SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const f
   hipStream_t st = sst_stream(stream);
 #define SST_PIPE_LAUNCH(S_, TW_)                                                                  \
   do {                                                                                            \
-    conv_pipe_kernel<S_, TW_, 0><<<grid, CONV_NT, 0, st>>>(a);                                    \
+    if (a.cb_per > 1) conv_pipe_kernel<S_, TW_, 0, true><<<grid, CONV_NT, 0, st>>>(a);            \
+    else conv_pipe_kernel<S_, TW_, 0, false><<<grid, CONV_NT, 0, st>>>(a);                        \
     SST_LAUNCH_CHECK("conv_pipe_kernel");                                                         \
     if (pl.ksplit > 1) {                                                                          \
       pipe_reduce_kernel<TW_, 0><<<a.total_tiles, CONV_NT, 0, st>>>(a);                           \
@@ -584,7 +601,8 @@ SST_API int sst_conv_s2_dgrad_pipe(const float* dy, const float* wp, float* dx, 
   hipStream_t st = sst_stream(stream);
 #define SST_S2D_LAUNCH(TW_)                                                                       \
   do {                                                                                            \
-    conv_pipe_kernel<1, TW_, 1><<<grid, CONV_NT, 0, st>>>(a);                                     \
+    if (a.cb_per > 1) conv_pipe_kernel<1, TW_, 1, true><<<grid, CONV_NT, 0, st>>>(a);             \
+    else conv_pipe_kernel<1, TW_, 1, false><<<grid, CONV_NT, 0, st>>>(a);                         \
     SST_LAUNCH_CHECK("conv_pipe_kernel (stride-2 data-gradient)");                                \
     if (pl.ksplit > 1) {                                                                          \
       pipe_reduce_kernel<TW_, 1><<<a.total_tiles * 4, CONV_NT, 0, st>>>(a);                       \

@@ -1,4 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
 cd $R
-for k in 8 6 5 4 3 2; do echo "defer=$k"; SST_DEFER_D_WGRAD=$k timeout -k 10 300 python3 bench.py --steps 60 --warmup 8 --no-cpu-baseline --no-roofline --no-secondary 2>/dev/null | cut -c100-230; done
+timeout -k 10 600 python3 -m pytest tests/test_conv_pipe_gpu.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -3 &&
+timeout -k 10 300 python3 tools/time_pipe.py 2>&1 | grep -v amdgpu.ids | cut -c1-175
