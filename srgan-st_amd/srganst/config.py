@@ -118,6 +118,8 @@ class Config:
         # backward (the discriminator branch is the longer one)
         # (= how many layers, counted from the first: the ones the backward chain reaches last; 0 = none, 8 = all)
         self.KERNEL.DEFER_D_WGRAD = int(os.environ.get("SST_DEFER_D_WGRAD", "8"))
+        # merged iteration: D's weight packing on the side stream beside the generator's forward
+        self.KERNEL.EARLY_D_PACK = os.environ.get("SST_EARLY_D_PACK", "1") != "0"
         self.KERNEL.REUSE_D_SR = os.environ.get("SST_REUSE_D_SR", "1") != "0"
         self.KERNEL.LR_ON_DEVICE = False    # True: the LR batch is synthesised from the GT batch on the GPU (sst_bicubic, same
                                             # values as dataset.py:28 on the 1/255 grid) instead of taking the loader's copy

@@ -501,15 +501,19 @@ class TrainEngine:
         if self._side_d is None:
             self._side_d = torch.cuda.Stream()
         early_gt = None
-        if cfg.KERNEL.EARLY_D_GT and "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS:
-            # D(gt)'s forward beside the generator's forward (a chain of short launches): the weights are packed here, on the main
-            # stream, for all three passes of the iteration
+        adv = "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS
+        if adv and (cfg.KERNEL.EARLY_D_PACK or cfg.KERNEL.EARLY_D_GT):
+            # D's weights are packed (one multi-tensor launch + one per stride-2 layer, 67 us) for all passes of the iteration on the
+            # side stream, beside the generator's forward, instead of in front of D(sr) on the critical path
             names = [n for n, _ in self.D.named_parameters()]
-            disc_graph._packs(self.D, dict(zip(names, [t.detach() for t in self.D.parameters()])), True)
             self._side_d.wait_stream(main)
             with torch.cuda.stream(self._side_d):
-                early_gt = self._d_gt_fwd()
+                disc_graph._packs(self.D, dict(zip(names, [t.detach() for t in self.D.parameters()])), True)
+                if cfg.KERNEL.EARLY_D_GT:            # D(gt)'s forward beside the generator's forward as well (measured slower, off)
+                    early_gt = self._d_gt_fwd()
         sr = self.G(self.lr)
+        if adv and (cfg.KERNEL.EARLY_D_PACK or cfg.KERNEL.EARLY_D_GT):
+            main.wait_stream(self._side_d)           # D(sr) below reads the packed weights
         ops.debug_stamp(1)
         total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
                                        adversarial=lambda crit: crit(self.D(sr), self.real))

@@ -338,9 +338,10 @@ def test_train_engine_schedules_are_bit_identical(interval):
     from srganst.loss import MSELoss, StructureTensorLoss
     from srganst.model import Discriminator, Generator
 
-    def run(gd, two, use_graph, reuse=True, early=True, defer=True):
+    def run(gd, two, use_graph, reuse=True, early=True, defer=True, pack_early=True):
         cfg = make_cfg(16, 2, 8)
         cfg.KERNEL.OVERLAP_GD, cfg.KERNEL.D_TWO_STREAMS, cfg.KERNEL.REUSE_D_SR, cfg.KERNEL.EARLY_D_GT = gd, two, reuse, early
+        cfg.KERNEL.EARLY_D_PACK = pack_early
         cfg.KERNEL.DEFER_D_WGRAD = {True: 8, False: 0}.get(defer, defer)      # layers whose last-pass weight gradients move to the other stream
         torch.manual_seed(1)
         D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
@@ -376,3 +377,7 @@ def test_train_engine_schedules_are_bit_identical(interval):
         out = run(True, False, use_graph, defer=defer)
         for k in ref:
             assert torch.equal(ref[k], out[k]), ("defer", defer, use_graph, k)
+    # ... and with D's weights packed in front of D(sr) on the main stream instead of beside the generator's forward (KERNEL.EARLY_D_PACK)
+    out = run(True, False, True, pack_early=False)
+    for k in ref:
+        assert torch.equal(ref[k], out[k]), ("late pack", k)
