@@ -63,7 +63,10 @@ def synth_batch(B, hr, device, seed):
     return gt.to(device), lr.to(device)
 
 
-def build_engine(workload, device, use_graph, hr):
+def build_engine(workload, device, use_graph, hr, share_d_sr=False):
+    """share_d_sr=False (the headline): the iteration runs all three discriminator forwards of the reference's step (train.py:136,
+    155, 158).  True: the engine's default schedule, in which the discriminator step works on the generator step's D(sr) pass
+    (KERNEL.REUSE_D_SR: bit-identical results, one forward less) - reported next to the headline, never as the headline."""
     from srganst.config import Config
     from srganst.engine import TrainEngine, WarmupEngine
     from srganst.loss import MSELoss, StructureTensorLoss
@@ -85,6 +88,7 @@ def build_engine(workload, device, use_graph, hr):
     cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
     cfg.add_g_criterion("ST", StructureTensorLoss(), 1.0 / 3.0)
     cfg.SOLVER.D_UPDATE_INTERVAL = 1
+    cfg.KERNEL.REUSE_D_SR = bool(share_d_sr)
     return TrainEngine(cfg, G, D, use_graph=use_graph), cfg
 
 
@@ -267,14 +271,14 @@ def timed_steps(eng, gt, lr, steps, warmup, world, device):
 STALL_EXIT = 3
 
 
-def secondary_leg(primary, workload, rank, world, device, args, B, steps=40, warmup=6, limit_s=240.0):
+def secondary_leg(primary, workload, rank, world, device, args, B, steps=40, warmup=6, limit_s=240.0, share_d_sr=False, key=None):
     """A second workload under the same timing protocol (the configs[1] SRResNet step next to the headline G+D+ST step).
     Every rank runs a watchdog: if the leg is not done after limit_s, rank 0 still prints the primary line (with the reason in
     it), the reason goes to stderr and the process exits NON-ZERO - a stall is a failed run, not a result."""
     import threading
     from srganst import dist as sdist
     done = threading.Event()
-    key = workload + "_step"
+    key = key or workload + "_step"
 
     def watchdog():
         if not done.wait(limit_s):
@@ -288,7 +292,7 @@ def secondary_leg(primary, workload, rank, world, device, args, B, steps=40, war
     threading.Thread(target=watchdog, daemon=True).start()
     res = None
     try:
-        eng, _ = build_engine(workload, device, use_graph=not args.no_graph, hr=args.hr)
+        eng, _ = build_engine(workload, device, use_graph=not args.no_graph, hr=args.hr, share_d_sr=share_d_sr)
         if world > 1:
             sdist.broadcast_module(eng.G)
             if hasattr(eng, "D"):
@@ -296,9 +300,14 @@ def secondary_leg(primary, workload, rank, world, device, args, B, steps=40, war
         gt, lr = synth_batch(B, args.hr, device, seed=100 + rank)
         el = timed_steps(eng, gt, lr, steps, warmup, world, device)
         imgs = B * world * steps / el
+        reused = bool(getattr(eng, "d_sr_reused", False))
         res = {"workload": workload_name(workload, args.hr, B), "value": imgs, "unit": "HR images/s", "ms_per_step": el / steps * 1e3,
                "steps": steps, "warmup": warmup, "n_gpus": world, "hip_graph": bool(eng.graph_active),
-               "step_tflops": flop_per_image(workload, args.hr) * imgs / 1e12}
+               "step_tflops": flop_per_image(workload, args.hr, reused) * imgs / 1e12}
+        if share_d_sr:
+            res["d_sr_forward"] = ("shared with the generator step's D(sr) pass: same input, same weights, deterministic kernels - results "
+                                   "bit-identical to the three-pass step (tests/test_discriminator_gpu.py), one discriminator forward less"
+                                   if reused else "run (sharing did not engage)")
         eng.close()
     except Exception as e:  # noqa: BLE001 - the primary line must still be printed; main() then exits non-zero
         res = {"error": f"{type(e).__name__}: {e}"}
@@ -318,6 +327,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run the big single weight gradients on a side stream (off: measured slower)")
     ap.add_argument("--no-overlap", action="store_true", help="(default) keep weight gradients on the main stream")
+    ap.add_argument("--share-d-sr", action="store_true",
+                    help="headline on the engine's default schedule (the discriminator step re-uses the generator step's D(sr) pass); "
+                         "without it the headline runs all three discriminator forwards of the reference's step and the shared "
+                         "schedule is reported as the secondary key srgan_shared_d_sr_step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", "--no-full-step", dest="no_secondary", action="store_true",
@@ -339,7 +352,7 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    eng, cfg = build_engine(args.workload, device, use_graph=not args.no_graph, hr=args.hr)
+    eng, cfg = build_engine(args.workload, device, use_graph=not args.no_graph, hr=args.hr, share_d_sr=args.share_d_sr)
     if world > 1:
         sdist.broadcast_module(eng.G)
         if hasattr(eng, "D"):
@@ -365,8 +378,9 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl, "global_batch": B * world, "hr": args.hr, "lr": args.hr // 4,
                           "parallelism": f"dp{world}", "hip_graph": graph_active, "d_update_interval": 1 if args.workload != "srresnet" else None,
-                          "d_sr_forward": ("shared with the generator step's D(sr) pass (same input and weights, bit-identical; SST_REUSE_D_SR=0 runs it again)"
-                                           if d_sr_reused else ("run" if args.workload != "srresnet" else None)),
+                          "d_sr_forward": ("shared with the generator step's D(sr) pass (same input and weights, bit-identical)"
+                                           if d_sr_reused else ("run: all three discriminator forwards of train.py:136,155,158"
+                                                                if args.workload != "srresnet" else None)),
                           "step_tflops": flop_per_image(args.workload, args.hr, d_sr_reused) * imgs / 1e12, "losses_last_step": losses}}
     if args.workload == "srgan" and not args.no_secondary:
         # BASELINE configs[1] (SRResNet, G only) in the same run, same protocol, fewer steps; at every N, so the driver's
@@ -375,6 +389,12 @@ def main():
         failed = failed or (extra is not None and "error" in extra)
         if rank == 0:
             out["srresnet_step"] = extra
+        if not args.share_d_sr:
+            # the engine's default schedule (one discriminator forward less, bit-identical results) under the same protocol
+            extra2 = secondary_leg(out, "srgan", rank, world, device, args, B, share_d_sr=True, key="srgan_shared_d_sr_step")
+            failed = failed or (extra2 is not None and "error" in extra2)
+            if rank == 0:
+                out["srgan_shared_d_sr_step"] = extra2
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = kernel_roofline(args.workload, device, args.hr, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
