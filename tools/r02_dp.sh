@@ -1,13 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
 cd $R
-python3 bench.py > $R/gpurun_out/b3.json 2> $R/gpurun_out/b3.err; echo rc=$?
-python3 - <<'PY'
-import json, os
-j = json.loads(open(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/b3.json").read().strip().split("\n")[-1])
-print(j["value"], j["ms_per_step"], j["config"]["d_sr_forward"], j["config"]["step_tflops"])
-print("shared:", j["srgan_shared_d_sr_step"])
-print("srresnet:", j["srresnet_step"]["value"], j["srresnet_step"]["ms_per_step"])
-print("roofline:", j["roofline"]["kernel"], j["roofline"]["frac"])
-print("cpu:", j["cpu_baseline"]["value"])
-PY
+for k in 0 2 3 4 6; do echo "sr defer=$k"; SST_DEFER_D_WGRAD_SR=$k python3 bench.py --steps 60 --no-cpu-baseline --no-roofline --no-secondary 2>/dev/null | cut -c150-215; done
+echo shared; for k in 0 2; do SST_DEFER_D_WGRAD_SR=$k python3 bench.py --share-d-sr --steps 60 --no-cpu-baseline --no-roofline --no-secondary 2>/dev/null | cut -c150-215; done
