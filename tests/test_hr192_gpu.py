@@ -98,7 +98,7 @@ def test_train_iteration_bench_size_vs_oracle():
     g64sd = {k: (v.double() if v.is_floating_point() else v) for k, v in g0.items()}
 
     chosen = None
-    for seed in range(42, 50):
+    for seed in range(42, 58):
         gen = torch.Generator().manual_seed(seed)
         gt = torch.rand(16, 3, 96, 96, generator=gen)
         lr = torch.rand(16, 3, 24, 24, generator=gen)
@@ -111,7 +111,7 @@ def test_train_iteration_bench_size_vs_oracle():
         if flips == 0:
             chosen = seed
             break
-    assert chosen is not None, "no input in 8 seeds on which the HIP and the fp64 forward clamp the same pixels"
+    assert chosen is not None, "no input in 16 seeds on which the HIP and the fp64 forward clamp the same pixels"
 
     def oracle_iter(dtype, device="cpu"):
         cast = lambda sd: {k: (v.to(dtype) if v.is_floating_point() else v).to(device) for k, v in sd.items()}
