@@ -469,6 +469,81 @@ __global__ __launch_bounds__(CONV_NT) void conv3_c3in_kernel(const float* __rest
   }
 }
 
+// 3x3 / stride 1 / pad 1 conv from 64 channels to 3 (round 2): the DATA-GRADIENT of the discriminator's first layer (model.py:32) -
+// the last step of the generator's adversarial backward, d loss / d sr.  With 3 output channels the general kernel fills 3 of 32
+// MFMA columns (8 TFLOP/s, 62 us at 96 px).  Here kx is folded into N: P[x'][(tx, ci)] = sum_{ty, co} dY[y-1+ty][x'][co] *
+// w[(ci, co, ty, tx)] for every input column x' = -1 .. W (9 of 16 columns of v_mfma_f32_16x16x4_f32, K = 3 x 64), then
+// dx[x][ci] = sum_tx P[x-1+tx][(tx, ci)] through LDS.  One wave = one output row: ceil((W+2)/16) M tiles x 48 MFMAs, the A operand
+// (dY) loaded straight from global memory as 16-B quads in MFMA layout (next tile's 12 quads in flight under the current tile's
+// MFMAs), the B operand (weights, 48 registers) read once from the ordinary mode-1 packed buffer.
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(CONV_NT) void conv3_to3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                            float* __restrict__ y, int B, int H, int W, int nmt) {
+  extern __shared__ __attribute__((aligned(16))) float pl_all[];        // [wave][nmt * 16][12]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= B * H) return;                                // no workgroup barrier below
+  const int b = row / H, oy = row - b * H;
+  const int lm = lane & 15, lg = lane >> 4;
+  float* const pl = pl_all + (size_t)wave * nmt * 16 * 12;
+  // B operand: column n = lm = tx*3 + ci (n < 9), K index of MFMA (ty, q, t): co = 16q + 4 lg + t.  packed mode-1 layout
+  // (conv_common.h: packed_index with o = ci < 3, i = co < 64): ((tap*8 + co/8)*256 + ((co&7)/4*32 + ci)*4 + (co&3)
+  float bw[3][4][4];
+  {
+    const int tx = lm / 3, ci = lm - tx * 3;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int co = 16 * q + 4 * lg + t, tap = ty * 3 + tx;
+          bw[ty][q][t] = lm < 9 ? wp[(size_t)(tap * 8 + (co >> 3)) * 256 + (((co & 7) >> 2) * 32 + ci) * 4 + (co & 3)] : 0.f;
+        }
+  }
+  auto load_tile = [&](int mt, f32x4c (&a)[3][4]) {
+    const int xp = mt * 16 + lm - 1;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int iy = oy - 1 + ty;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)xp < (unsigned)W;
+      const float* src = x + (((size_t)b * H + (ok ? iy : 0)) * W + (ok ? xp : 0)) * 64 + 4 * lg;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4c v = *reinterpret_cast<const f32x4c*>(src + 16 * q);
+        a[ty][q] = ok ? v : f32x4c{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  f32x4c ac[3][4], an[3][4];
+  load_tile(0, ac);
+  for (int mt = 0; mt < nmt; ++mt) {
+    if (mt + 1 < nmt) load_tile(mt + 1, an);
+    f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[ty][q][t], bw[ty][q][t], acc, 0, 0, 0);
+    // acc[r]: row x' (local) = mt*16 + 4 lg + r, column n = lm
+    if (lm < 9) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pl[(mt * 16 + 4 * lg + r) * 12 + lm] = acc[r];
+    }
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ac[ty][q] = an[ty][q];
+  }
+  // horizontal fold (LDS ops of a wave complete in order): dx[x][ci] = sum_tx P[x + tx][(tx, ci)]  (local x' index = x' + 1)
+  float* const out = y + ((size_t)b * H + oy) * W * 3;
+  for (int i = lane; i < 3 * W; i += 64) {
+    const int xo = i / 3, ci = i - xo * 3;
+    out[i] = (pl[xo * 12 + ci] + pl[(xo + 1) * 12 + 3 + ci]) + pl[(xo + 2) * 12 + 6 + ci];
+  }
+}
+
 // w [Cout][Cin][3][3] (reference layout) -> packed.  mode 0: forward.  mode 1: data-gradient of a stride-1
 // conv (outputs = Cin, inputs = Cout, taps rotated 180 degrees).  Stride-2 data-gradients use
 // pack_s2_dgrad_kernel below (one compact tap list per output-pixel parity class).
@@ -705,6 +780,16 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   hipStream_t st = sst_stream(stream);
   const size_t extra_lds = (size_t)(dbg_bits >> 4) * 1024;   // dev knob: pad LDS to cap workgroups per CU
   a.dbg = dbg_bits & 15;
+  if (ksize == 3 && stride == 1 && Cin == 64 && Cout == 3 && out_mode == OUT_NHWC && !bias && !in_scale && in_act == ACT_NONE && !residual &&
+      !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !getenv("SST_NO_TO3")) {
+    const int nmt = (W + 2 + 15) / 16;
+    const size_t lds = (size_t)4 * nmt * 16 * 12 * sizeof(float);
+    if (lds <= 60 * 1024) {
+      conv3_to3_kernel<<<(unsigned)((B * H + 3) / 4), CONV_NT, lds, st>>>(x, wp, y, B, H, W, nmt);
+      SST_LAUNCH_CHECK("conv3_to3_kernel");
+      return SST_OK;
+    }
+  }
   if (ksize == 3 && stride == 1 && Cin == 3 && (Cout & 3) == 0 && CONV_NT % (Cout >> 2) == 0 && out_mode == OUT_NHWC && !in_scale &&
       in_act == ACT_NONE && !residual && !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !getenv("SST_NO_C3IN")) {
     const size_t lds = (size_t)3 * ((W + 2) * 3 + 1) * sizeof(float);
@@ -738,6 +823,9 @@ SST_API const char* sst_conv_kernel_name(int B, int H, int W, int Cin, int Cout,
   a.Ho = (H + 2 * p - ksize) / stride + 1;
   a.Wo = (W + 2 * p - ksize) / stride + 1;
   a.in2 = fused_in ? reinterpret_cast<const float*>(1) : nullptr;
+  if (ksize == 3 && stride == 1 && Cin == 64 && Cout == 3 && out_mode == OUT_NHWC && !fused_in && !getenv("SST_NO_TO3") &&
+      (size_t)4 * ((W + 2 + 15) / 16) * 16 * 12 * sizeof(float) <= 60 * 1024)
+    return "conv3_to3_kernel";       // (when called plain, as the data-gradient of a 3-channel-input layer is)
   if (ksize == 3 && stride == 1 && Cin == 3 && (Cout & 3) == 0 && CONV_NT % (Cout >> 2) == 0 && out_mode == OUT_NHWC && !fused_in)
     return "conv3_c3in_kernel";      // (when called without input affine / activation / residual / statistics)
   if (out_mode == OUT_NHWC) {

@@ -572,6 +572,32 @@ def test_conv_fwd_three_channel_input(ops, case, monkeypatch):
     assert rel_err(y2.cpu(), y.cpu()) < TOL
 
 
+@pytest.mark.parametrize("case", [(2, 8, 32), (16, 96, 96), (3, 5, 20), (1, 7, 192), (2, 3, 14), (5, 1, 16)])
+def test_conv_64_to_3_channels_kernel(ops, case, monkeypatch):
+    """3x3 conv from 64 channels to 3 with kx folded into the MFMA columns (conv3_to3_kernel): as the data-gradient of the
+    discriminator's first layer (reference model.py:32, mode-1 packed weights) against autograd in fp64, as a plain forward conv
+    (mode-0 pack) against conv2d, and against the general kernel (SST_NO_TO3); borders, widths that are not multiples of 16."""
+    from srganst import _abi
+    B, H, W = case
+    g = torch.Generator().manual_seed(101)
+    assert _abi.lib().sst_conv_kernel_name(B, H, W, 64, 3, 3, 1, 0, 0) == b"conv3_to3_kernel"
+    x = torch.randn(B, 3, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(64, 3, 3, 3, generator=g) / 5.0
+    dy = torch.randn(B, 64, H, W, generator=g)
+    F.conv2d(x, w.double(), None, 1, 1).backward(dy.double())
+    dyd = nhwc(dy).cuda()
+    wd = ops.pack_conv(w.cuda(), 1)
+    dx = ops.conv_fwd(dyd, wd, 3, 3, 1)[0]
+    assert tuple(dx.shape) == (B, H, W, 3) and rel_err(nchw(dx.cpu()), x.grad) < TOL
+    w2 = torch.randn(3, 64, 3, 3, generator=g) / 24.0                        # the same kernel as a forward conv
+    y = ops.conv_fwd(dyd, ops.pack_conv(w2.cuda()), 3, 3, 1)[0]
+    assert rel_err(nchw(y.cpu()), F.conv2d(dy.double(), w2.double(), None, 1, 1)) < TOL
+    monkeypatch.setenv("SST_NO_TO3", "1")
+    assert _abi.lib().sst_conv_kernel_name(B, H, W, 64, 3, 3, 1, 0, 0) != b"conv3_to3_kernel"
+    dx_old = ops.conv_fwd(dyd, wd, 3, 3, 1)[0]
+    assert rel_err(dx_old.cpu(), dx.cpu()) < TOL
+
+
 @pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (1, 12, 12, 128, 64), (2, 9, 13, 64, 128), (1, 6, 6, 256, 256)])
 def test_conv_s2_dgrad_fused_stage(ops, case):
     """BatchNorm-backward stage around the stride-2 data-gradient (apply on load, dy side output, partial sums of the result
