@@ -99,6 +99,13 @@ int sst_conv_s2_dgrad_pipe_supported(int B, int H, int W, int Cin, int Cout);
 int64_t sst_conv_s2_dgrad_pipe_ws_floats(int B, int H, int W, int Cin, int Cout);
 int sst_conv_s2_dgrad_pipe(const float* dy, const float* wp, float* dx, float* ws, int B, int H, int W, int Cin, int Cout,
                            void* stream);
+/* ... with the BatchNorm / activation backward partials of dx against epi_y (the saved output of the layer below, [B,H,W,Cin]) written by
+ * the epilogue: epi_partial [sst_conv_s2_dgrad_pipe_stat_tiles()][3][Cin], the layout sst_bwd_finalize consumes (null: none). */
+int sst_conv_s2_dgrad_pipe_stat_tiles(int B, int H, int W, int Cin, int Cout);
+int sst_conv_s2_dgrad_pipe_bwdstats(const float* dy, const float* wp, float* dx, float* ws, const float* epi_y,
+                                    const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                                    float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
+                                    int Cout, void* stream);
 /* stride-1 data-gradient (mode 1 weights) whose epilogue also emits the BatchNorm/activation BACKWARD partial sums of
  * its result g against the saved conv output epi_y: epi_partial [sst_conv_stat_tiles][3][Cout] = per-tile sums of
  * (gz, gz*epi_y, g*min(z,0)) - the layout sst_bwd_finalize consumes (replaces a separate sst_bwd_reduce pass). */

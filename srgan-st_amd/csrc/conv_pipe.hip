@@ -110,19 +110,21 @@ __device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float v[4], int
   const int px = lane & 31;
   const int r = r0 + px / TW, ox = ox0 + px % TW;
   const bool pix_ok = r < a.R && ox < a.Wo;
+  size_t obase;
   if (MODE) {        // stride-2 data-gradient: class (sy, sx) pixel (r, ox) of the tall class grid -> dX pixel (2r + sy, 2ox + sx)
-    const size_t o = ((size_t)(2 * r + (cls >> 1)) * (2 * a.Wo) + 2 * ox + (cls & 1)) * a.Cout + c0;
-    if (pix_ok) *reinterpret_cast<f32x4*>(a.y + o) = f32x4{v[0], v[1], v[2], v[3]};
-    return;
+    obase = ((size_t)(2 * r + (cls >> 1)) * (2 * a.Wo) + 2 * ox + (cls & 1)) * a.Cout + c0;
+    if (pix_ok) *reinterpret_cast<f32x4*>(a.y + obase) = f32x4{v[0], v[1], v[2], v[3]};
   }
-  if (a.bias) {
+  if (!MODE && a.bias) {
     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] += bv[j];
   }
-  const size_t obase = ((size_t)r * a.Wo + ox) * a.Cout + c0;
-  if (pix_ok) *reinterpret_cast<f32x4*>(a.y + obase) = f32x4{v[0], v[1], v[2], v[3]};
-  if (a.stats) {
+  if (!MODE) {
+    obase = ((size_t)r * a.Wo + ox) * a.Cout + c0;
+    if (pix_ok) *reinterpret_cast<f32x4*>(a.y + obase) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+  if (!MODE && a.stats) {
     // per-tile (sum, centred M2) per output channel over the tile's valid pixels (combined by bn_finalize with Chan's formula)
     const int nvalid = min(TH, a.R - r0) * min(TW, a.Wo - ox0);
     f32x4 s1, m2;
@@ -165,8 +167,9 @@ __device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float v[4], int
       q[2][j] = half_sum(q2);
     }
     if (px == 0) {
+      const size_t prow = MODE ? (size_t)mt * 4 + cls : (size_t)mt;     // MODE 1: one row of partials per (tile, parity class)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) *reinterpret_cast<f32x4*>(a.epi_partial + ((size_t)mt * 3 + k) * a.Cout + c0) = q[k];
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<f32x4*>(a.epi_partial + (prow * 3 + k) * a.Cout + c0) = q[k];
     }
   }
 }
@@ -582,9 +585,15 @@ SST_API int64_t sst_conv_s2_dgrad_pipe_ws_floats(int B, int H, int W, int Cin, i
   const PipePlan pl = pipe_plan_s2d(B, H, W, Cin, Cout);
   return (pl.tw && pl.ksplit > 1) ? (int64_t)pl.ksplit * pl.n_mt * pl.nfc * 4 * 1024 : 0;
 }
-SST_API int sst_conv_s2_dgrad_pipe(const float* dy, const float* wp, float* dx, float* ws, int B, int H, int W, int Cin, int Cout,
-                                   void* stream) {
+SST_API int sst_conv_s2_dgrad_pipe_stat_tiles(int B, int H, int W, int Cin, int Cout) { return pipe_plan_s2d(B, H, W, Cin, Cout).n_mt * 4; }
+// ... with the BatchNorm / activation backward partials of dx against epi_y (the saved output of the layer below, [B,H,W,Cin]) in
+// the epilogue: epi_partial [sst_conv_s2_dgrad_pipe_stat_tiles()][3][Cin], the layout sst_bwd_finalize consumes (null: none).
+SST_API int sst_conv_s2_dgrad_pipe_bwdstats(const float* dy, const float* wp, float* dx, float* ws, const float* epi_y,
+                                            const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                                            float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
+                                            int Cout, void* stream) {
   SST_REQUIRE(dy && wp && dx, "sst_conv_s2_dgrad_pipe: null pointer");
+  SST_REQUIRE(!epi_partial || (epi_y && ((epi_scale == nullptr) == (epi_shift == nullptr))), "sst_conv_s2_dgrad_pipe: backward partials need epi_y");
   const PipePlan pl = pipe_plan_s2d(B, H, W, Cin, Cout);
   SST_REQUIRE(pl.tw, "sst_conv_s2_dgrad_pipe: shape B=%d H=%d W=%d Cin=%d Cout=%d is not taken by the pipelined kernel", B, H, W, Cin, Cout);
   SST_REQUIRE(pl.ksplit == 1 || ws, "sst_conv_s2_dgrad_pipe: this shape splits K over workgroups and needs the workspace");
@@ -592,6 +601,8 @@ SST_API int sst_conv_s2_dgrad_pipe(const float* dy, const float* wp, float* dx, 
   PipeArgs a{};
   a.x = dy; a.wp = wp + sst_conv_s2_dgrad_pipe_section(Cout, Cin); a.y = dx; a.ws = ws;
   a.in_act = ACT_NONE;
+  a.epi_y = epi_y; a.epi_scale = epi_scale; a.epi_shift = epi_shift; a.epi_slope = epi_slope; a.epi_slope_const = epi_slope_const;
+  a.epi_act = epi_act; a.epi_partial = epi_partial;
   a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.Cout = Cin;      // GEMM view: K = dY channels, N = dX channels
   a.Ho = a.H; a.Wo = a.W; a.R = B * a.Ho;
   a.tiles_x = pl.tiles_x; a.n_mt = pl.n_mt; a.nfc = pl.nfc; a.total_tiles = pl.n_mt * pl.nfc; a.ncb = pl.ncb;
@@ -613,3 +624,8 @@ SST_API int sst_conv_s2_dgrad_pipe(const float* dy, const float* wp, float* dx, 
 #undef SST_S2D_LAUNCH
   return SST_OK;
 }
+SST_API int sst_conv_s2_dgrad_pipe(const float* dy, const float* wp, float* dx, float* ws, int B, int H, int W, int Cin, int Cout,
+                                   void* stream) {
+  return sst_conv_s2_dgrad_pipe_bwdstats(dy, wp, dx, ws, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, B, H, W, Cin, Cout, stream);
+}
+

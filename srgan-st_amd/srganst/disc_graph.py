@@ -221,7 +221,15 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
             else:
                 g = ops.conv_fwd(dy, wd[f"features.{ci}.weight"], w.shape[1], 3, 1)[0]
         else:
-            g = ops.conv_s2_dgrad(dy, ws2[f"features.{ci}.weight"], xin.shape[1], xin.shape[2], w.shape[1])
+            # the backward partials of g against the layer below come out of the data-gradient's epilogue where the pipelined kernel
+            # takes the shape (no separate reduce pass over g and y); they are only needed when the layer below has a BatchNorm
+            # or parameter gradients are wanted (its bias)
+            prev = sv["layers"][li - 1] if li > 0 else None
+            epi = None
+            if prev is not None and (prev["bi"] is not None or wg):
+                epi = dict(y=prev["y"], scale=prev["scale"], shift=prev["shift"], slope_const=LRELU, act=1)
+            out = ops.conv_s2_dgrad(dy, ws2[f"features.{ci}.weight"], xin.shape[1], xin.shape[2], w.shape[1], epi=epi)
+            g, part = out if epi is not None else (out, None)
         if li == 0:
             dx = ops.transpose(g, to_nchw=True)
     ops.join_side()

@@ -452,29 +452,44 @@ def pack_conv_s2_dgrad(w, out=None):
     return wp
 
 
-def conv_s2_dgrad(dy, wp, H, W, cin):
-    """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] for y = conv3x3(x, stride 2, pad 1)."""
+S2D_EPI = os.environ.get("SST_S2D_EPI", "0") != "0"
+
+
+def conv_s2_dgrad(dy, wp, H, W, cin, epi=None):
+    """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] for y = conv3x3(x, stride 2, pad 1).
+    epi = dict(y, scale, shift, slope, slope_const, act): also the BatchNorm / activation backward partials of dx against epi["y"]
+    ([tiles,3,cin], the layout bwd_finalize consumes) where the pipelined kernel takes the shape -> (dx, partial | None)."""
     B, ho, wo, cout = dy.shape
     dx = _f32(B, H, W, cin, like=dy)
     L = _abi.lib()
     if os.environ.get("SST_CONV_PIPE", "1") != "0" and L.sst_conv_s2_dgrad_pipe_supported(B, H, W, cin, cout):
         nws = L.sst_conv_s2_dgrad_pipe_ws_floats(B, H, W, cin, cout)
         ws = _f32(nws, like=dy) if nws else None
-        args = (ptr(dy), ptr(wp), ptr(dx), ptr(ws), B, H, W, cin, cout)
+        partial = None
+        # measured on the G + D + ST step: 5.34 ms with the partials in the epilogue against 5.30 ms with the separate reduce pass (four
+        # scattered epilogues per unit cost more than the three reduce launches they replace) - off unless SST_S2D_EPI=1
+        if epi is not None and S2D_EPI:
+            partial = _f32(L.sst_conv_s2_dgrad_pipe_stat_tiles(B, H, W, cin, cout), 3, cin, like=dy)
+        e = epi or {}
+        args = (ptr(dy), ptr(wp), ptr(dx), ptr(ws), ptr(e.get("y")) if partial is not None else None,
+                ptr(e.get("scale")) if partial is not None else None, ptr(e.get("shift")) if partial is not None else None,
+                ptr(e.get("slope")) if partial is not None else None, float(e.get("slope_const", 0.0)), int(e.get("act", 0)),
+                ptr(partial), B, H, W, cin, cout)
         e0 = _prof_begin()
-        check(L.sst_conv_s2_dgrad_pipe(*args, stream_ptr()), "sst_conv_s2_dgrad_pipe")
+        check(L.sst_conv_s2_dgrad_pipe_bwdstats(*args, stream_ptr()), "sst_conv_s2_dgrad_pipe")
         if PROFILE is not None or TRACE is not None:
             name, flops = f"conv_pipe_kernel<1, {L.sst_conv_s2_dgrad_pipe_supported(B, H, W, cin, cout)}, 1>", 2.0 * B * ho * wo * cout * cin * 9
             _prof_end(e0, name, flops)
-            _trace(name, flops, lambda: L.sst_conv_s2_dgrad_pipe(*args, stream_ptr()), dy, wp, dx, ws)
-        return dx
+            _trace(name, flops, lambda: L.sst_conv_s2_dgrad_pipe_bwdstats(*args, stream_ptr()), dy, wp, dx, ws, partial,
+                   e.get("y"), e.get("scale"), e.get("shift"), e.get("slope"))
+        return (dx, partial) if epi is not None else dx
     e0 = _prof_begin()
     check(_abi.lib().sst_conv_s2_dgrad(ptr(dy), ptr(wp), ptr(dx), B, H, W, cin, cout, stream_ptr()), "sst_conv_s2_dgrad")
     if PROFILE is not None or TRACE is not None:
         name, flops = _abi.lib().sst_conv_s2_dgrad_kernel_name(B, H, W, cin, cout, 0).decode(), 2.0 * B * ho * wo * cout * cin * 9
         _prof_end(e0, name, flops)
         _trace(name, flops, lambda: _abi.lib().sst_conv_s2_dgrad(ptr(dy), ptr(wp), ptr(dx), B, H, W, cin, cout, stream_ptr()), dy, wp, dx)
-    return dx
+    return (dx, None) if epi is not None else dx
 
 
 def conv_s2_dgrad_fused(g, y2, wp, H, W, cin, cA=None, cB=None, cC=None, in_scale=None, in_shift=None, in_slope=None,

@@ -163,6 +163,20 @@ def test_conv_pipe_stride2_dgrad(ops, case, monkeypatch):
     dx = ops.conv_s2_dgrad(dyd, wp, H, W, Cin)
     assert rel_err(nchw(dx.cpu()), x.grad) < TOL
     assert torch.equal(dx, ops.conv_s2_dgrad(dyd, wp, H, W, Cin))          # fixed-order reductions: bit-identical relaunch
+    # the same launch with the BatchNorm / LeakyReLU backward partials of dx against the saved output of the layer below in its
+    # epilogue: dx bit-identical, the column sums of the partials equal to the separate reduce pass over (dx, y)
+    monkeypatch.setattr(ops, "S2D_EPI", True)
+    yprev = torch.randn(B, H, W, Cin, generator=g).cuda()
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).cuda(), (torch.randn(Cin, generator=g) * 0.3).cuda()
+    for kw in (dict(scale=sc, shift=sh), dict(scale=None, shift=None)):
+        dx2, part = ops.conv_s2_dgrad(dyd, wp, H, W, Cin, epi=dict(y=yprev, slope_const=0.2, act=1, **kw))
+        assert torch.equal(dx2, dx)
+        if tw:
+            assert part is not None and part.shape[0] == L.sst_conv_s2_dgrad_pipe_stat_tiles(B, H, W, Cin, Cout)
+            ref = ops.bwd_reduce(dx, yprev, scale=kw["scale"], shift=kw["shift"], slope_const=0.2, act=1).double().sum(0)
+            assert rel_err(part.double().sum(0).cpu(), ref.cpu()) < 1e-5
+        else:
+            assert part is None
     monkeypatch.setenv("SST_CONV_PIPE", "0")
     dx0 = ops.conv_s2_dgrad(dyd, wp, H, W, Cin)
     assert rel_err(dx.cpu(), dx0.cpu()) < 1e-5
