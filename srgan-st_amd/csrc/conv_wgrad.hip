@@ -724,6 +724,7 @@ struct WgS2Args {
   int B, H, W, Cin, Cout, Ho, Wo;
   int tiles_x, tiles_img, ntiles, tpc;          // tiles per row of tiles / per image / in total / per chunk
   int dbg;                                      // ablation bits (SST_WGRAD_S2_DBG, dev): 1 no staging stores, 2 no global loads, 4 no MFMA loop, 8 no exchange
+  float* dw; int accumulate;                    // one chunk only (no K split over workgroups): dW[co][ci][tap] written (or added to) directly, no slab
 };
 
 // S2_NW waves per workgroup: 8 = two per SIMD, one stages while the other multiplies (256 registers each); 4 = one per SIMD with
@@ -901,7 +902,12 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_tile_kernel(WgS2Args
       float v = sb[row * 33 + li];
 #pragma unroll
       for (int w = 1; w < S2_NW; ++w) v += sb[(w * 32 + row) * 33 + li];
-      out[((size_t)tap * a.Cout + co0 + row) * a.Cin + ci0 + li] = v;
+      if (a.dw) {
+        float* d = a.dw + ((size_t)(co0 + row) * a.Cin + ci0 + li) * 9 + tap;
+        *d = a.accumulate ? *d + v : v;
+      } else {
+        out[((size_t)tap * a.Cout + co0 + row) * a.Cin + ci0 + li] = v;
+      }
     }
   }
 }
@@ -1053,11 +1059,18 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
     s2.in_slope_const = in_slope_const; s2.in_act = in_act;
     s2.B = B; s2.H = H; s2.W = W; s2.Cin = Cin; s2.Cout = Cout; s2.Ho = a.Ho; s2.Wo = a.Wo;
     s2.dbg = getenv("SST_WGRAD_S2_DBG") ? atoi(getenv("SST_WGRAD_S2_DBG")) : 0;
+    const bool direct = p2.nchunk == 1 && !getenv("SST_WGRAD_TILE_NO_DIRECT");
+    s2.dw = direct ? dw : nullptr;
+    s2.accumulate = accumulate & 1;
     s2.tiles_x = a.Wo / p2.tw; s2.tiles_img = (a.Ho / p2.th) * s2.tiles_x; s2.ntiles = p2.ntiles; s2.tpc = p2.tpc;
     int rc;
     if (stride == 2) rc = p2.tw == 8 ? launch_wgrad_s2_t<2, 2, 8, 8>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<2, 2, 6, 8>(s2, p2, sst_stream(stream));
     else rc = p2.tw == 8 ? launch_wgrad_s2_t<1, 4, 8, 8>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<1, 4, 6, 8>(s2, p2, sst_stream(stream));
     if (rc != SST_OK) return rc;
+    if (direct) {
+      SST_LAUNCH_CHECK("conv_wgrad_tile_kernel");
+      return SST_OK;                            // the single chunk went straight into dW
+    }
     nchunk = p2.nchunk;
   } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && k3c3_mfma_applies(W, Cout)) {
     nchunk = k3c3_mfma_chunks(B, H, W);
