@@ -317,7 +317,19 @@ class TrainEngine:
         self.g_opt.zero_grad(set_to_none=True)
         self.D.__dict__["_packs_fresh"] = False
         self.D.__dict__["_keep_pass"], self.D.__dict__["_last_pass"] = True, None      # _d_fwd_cls re-uses the D(sr) pass
+        early_pack = cfg.KERNEL.EARLY_D_PACK and "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS
+        if early_pack:                             # D's weight packing beside the generator's forward (as in _iter_gd)
+            from . import disc_graph
+            main = torch.cuda.current_stream()
+            if self._side_d is None:
+                self._side_d = torch.cuda.Stream()
+            names = [n for n, _ in self.D.named_parameters()]
+            self._side_d.wait_stream(main)
+            with torch.cuda.stream(self._side_d):
+                disc_graph._packs(self.D, dict(zip(names, [t.detach() for t in self.D.parameters()])), True)
         sr = self.G(self.lr)
+        if early_pack:
+            main.wait_stream(self._side_d)
         total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
                                        adversarial=lambda crit: crit(self.D(sr), self.real))
         self.D.__dict__["_keep_pass"] = False
