@@ -35,6 +35,16 @@ int sst_st_loss_fwd(const float* sr, const float* gt, float* loss, float* gS, fl
 int sst_st_loss_bwd(const float* sr, const float* gS, float* dsr, const float* scale_dev,
                     float scale_host, int accumulate, int B, int H, int W, float sigma, float rho,
                     void* stream);
+/* The same two launches with the pixel criterion of the step riding along (reference train.py:129-140 evaluates "Pixel" =
+ * MSE / L1, config.py:88-90, and "ST" on the same sr / gt): pix_mode 0 = MSE, 1 = L1.
+ * fwd: also pix_loss[0] = mean over all B*3*H*W elements (pix_partials: as many floats as `partials`).
+ * bwd: dsr (+)= (scale_dev ? *scale_dev : 1) * (scale_host * d ST-loss / d sr + pix_weight * d pixel criterion / d sr).   */
+int sst_st_pixel_loss_fwd(const float* sr, const float* gt, float* loss, float* gS, float* partials, unsigned* counter,
+                          float* pix_loss, float* pix_partials, int pix_mode, int B, int H, int W, float sigma, float rho,
+                          int normalize, void* stream);
+int sst_st_pixel_loss_bwd(const float* sr, const float* gt, const float* gS, float* dsr, const float* scale_dev, float scale_host,
+                          float pix_weight, int pix_mode, int accumulate, int B, int H, int W, float sigma, float rho,
+                          void* stream);
 
 /* ---- convolution (fp32 MFMA implicit GEMM, NHWC) --------------------------------------------------
  * Replaces the cuDNN/oneDNN kernels behind nn.Conv2d fwd/bwd of model.py:32-56,101,113,127,159,173,176.

@@ -130,11 +130,16 @@ constexpr int st_fwd_lds_floats() {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pixel criterion riding along (reference train.py:129-140 evaluates "Pixel" and "ST" on the same sr / gt): mode < 0 none, 0 MSE,
+// 1 L1.  The tile's own pixels are re-read per channel (cache hits: the gray patch was just built from them); the partial sums
+// share the structure-tensor term's last-block ticket.
+struct StPix { float* loss; float* partials; int mode; };
+
 template <int R1, int R2>
 __global__ __launch_bounds__(NT) void st_loss_fwd_kernel(const float* __restrict__ sr, const float* __restrict__ gt,
                                                          float* __restrict__ gS, float* __restrict__ loss,
                                                          float* __restrict__ partials, unsigned* __restrict__ counter,
-                                                         int B, int H, int W, int normalize, StTaps<R1, R2> tp) {
+                                                         int B, int H, int W, int normalize, StTaps<R1, R2> tp, StPix pix) {
   __shared__ float lds[st_fwd_lds_floats<R1, R2>()];
   __shared__ float red[NT / 64];
   const int b = blockIdx.z, y0 = blockIdx.y * T, x0 = blockIdx.x * T;
@@ -144,11 +149,19 @@ __global__ __launch_bounds__(NT) void st_loss_fwd_kernel(const float* __restrict
   tile_structure_tensor<R1, R2>(gt + img_off, H, W, y0, x0, tp, lds, J2);
 
   const float eps = 1e-12f;
-  float lsum = 0.f;
+  float lsum = 0.f, psum = 0.f;
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int p = threadIdx.x + j * NT, y = y0 + (p >> 5), x = x0 + (p & 31);
     if (y >= H || x >= W) continue;
+    if (pix.mode >= 0) {
+      const size_t o = img_off + (size_t)y * W + x, hw = (size_t)H * W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = sr[o + c * hw] - gt[o + c * hw];
+        psum += pix.mode == 0 ? d * d : fabsf(d);
+      }
+    }
     const float a1 = J1[j][0], b1 = J1[j][1], c1 = J1[j][2];
     const float a2 = J2[j][0], b2 = J2[j][1], c2 = J2[j][2];
     // normalize                                                             utils.py:236-239
@@ -209,10 +222,22 @@ __global__ __launch_bounds__(NT) void st_loss_fwd_kernel(const float* __restrict
   __shared__ unsigned s_flag;
   const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
   const unsigned me = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  if (threadIdx.x == 0) partials[me] = bsum;
+  float pb = 0.f;
+  if (pix.mode >= 0) pb = block_sum<NT>(psum, red);
+  if (threadIdx.x == 0) {
+    partials[me] = bsum;
+    if (pix.mode >= 0) pix.partials[me] = pb;
+  }
   float tot;
-  if (last_block_total<NT>(partials, counter, nblk, &s_flag, red, tot) && threadIdx.x == 0)
-    loss[0] = tot / ((float)B * (float)H * (float)W);
+  if (last_block_total<NT>(partials, counter, nblk, &s_flag, red, tot)) {
+    if (threadIdx.x == 0) loss[0] = tot / ((float)B * (float)H * (float)W);
+    if (pix.mode >= 0) {                                   // same ticket: every workgroup's stores are visible here
+      float t2 = 0.f;
+      for (unsigned i = threadIdx.x; i < nblk; i += NT) t2 += load_agent(pix.partials + i);
+      t2 = block_sum<NT>(t2, red);
+      if (threadIdx.x == 0) pix.loss[0] = t2 / (3.f * (float)B * (float)H * (float)W);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -223,11 +248,13 @@ constexpr int st_bwd_lds_floats() {
 }
 
 // d(sr) (+)= gray_w[c] * scale * adjoint(structure tensor)(gS).   scale = scale_host * (scale_dev ? *scale_dev : 1)
+// pix_gt != null: dsr also receives pix_scale * (scale_dev ? *scale_dev : 1) * d pixel_criterion / d sr (pix_scale = weight / numel)
 template <int R1, int R2>
 __global__ __launch_bounds__(NT) void st_loss_bwd_kernel(const float* __restrict__ sr, const float* __restrict__ gS,
                                                          float* __restrict__ dsr, const float* __restrict__ scale_dev,
                                                          float scale_host, int accumulate, int B, int H, int W,
-                                                         StTaps<R1, R2> tp) {
+                                                         StTaps<R1, R2> tp, const float* __restrict__ pix_gt, float pix_scale,
+                                                         int pix_mode) {
   constexpr int R = R1 + R2;
   constexpr int EW = T + 2 * R1;    // region where dIx,dIy are needed
   constexpr int SW = T + 2 * R;     // gS patch edge
@@ -337,14 +364,24 @@ __global__ __launch_bounds__(NT) void st_loss_bwd_kernel(const float* __restrict
     if (y < H && x < W) {
       const size_t o = img_off + (size_t)y * W + x;
       const float v = dg_ * scale;
+      float pv[3] = {0.f, 0.f, 0.f};
+      if (pix_gt) {
+        float psc = pix_scale;
+        if (scale_dev) psc *= scale_dev[0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float d = sr[o + c * hw] - pix_gt[o + c * hw];
+          pv[c] = pix_mode == 0 ? 2.f * d * psc : (d > 0.f ? psc : (d < 0.f ? -psc : 0.f));
+        }
+      }
       if (accumulate) {
-        dsr[o] += 0.2989f * v;
-        dsr[o + hw] += 0.587f * v;
-        dsr[o + 2 * hw] += 0.114f * v;
+        dsr[o] += 0.2989f * v + pv[0];
+        dsr[o + hw] += 0.587f * v + pv[1];
+        dsr[o + 2 * hw] += 0.114f * v + pv[2];
       } else {
-        dsr[o] = 0.2989f * v;
-        dsr[o + hw] = 0.587f * v;
-        dsr[o + 2 * hw] = 0.114f * v;
+        dsr[o] = 0.2989f * v + pv[0];
+        dsr[o + hw] = 0.587f * v + pv[1];
+        dsr[o + 2 * hw] = 0.114f * v + pv[2];
       }
     }
   }
@@ -389,19 +426,18 @@ SST_API int sst_st_loss_workspace(int B, int H, int W, int64_t* partial_floats) 
   return SST_OK;
 }
 
-SST_API int sst_st_loss_fwd(const float* sr, const float* gt, float* loss, float* gS, float* partials,
-                            unsigned* counter, int B, int H, int W, float sigma, float rho, int normalize,
-                            void* stream) {
+static int st_loss_fwd_impl(const float* sr, const float* gt, float* loss, float* gS, float* partials, unsigned* counter, int B, int H,
+                            int W, float sigma, float rho, int normalize, StPix pix, void* stream) {
   SST_REQUIRE(sr && gt && loss && gS && partials && counter, "sst_st_loss_fwd: null pointer");
   SST_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535, "sst_st_loss_fwd: bad shape B=%d H=%d W=%d", B, H, W);
   const int r1 = radius_of(sigma), r2 = radius_of(rho);
   dim3 grid((W + T - 1) / T, (H + T - 1) / T, B);
   if (r1 == 2 && r2 == 8) {
     st_loss_fwd_kernel<2, 8><<<grid, NT, 0, sst_stream(stream)>>>(sr, gt, gS, loss, partials, counter, B, H, W,
-                                                                    normalize, make_taps<2, 8>(sigma, rho));
+                                                                    normalize, make_taps<2, 8>(sigma, rho), pix);
   } else if (r1 == 4 && r2 == 10) {
     st_loss_fwd_kernel<4, 10><<<grid, NT, 0, sst_stream(stream)>>>(sr, gt, gS, loss, partials, counter, B, H, W,
-                                                                     normalize, make_taps<4, 10>(sigma, rho));
+                                                                     normalize, make_taps<4, 10>(sigma, rho), pix);
   } else {
     return sst_set_error(SST_ERR_UNSUPPORTED, "sst_st_loss_fwd: (sigma,rho)=(%g,%g) -> radii (%d,%d) not built", sigma,
                          rho, r1, r2);
@@ -410,8 +446,24 @@ SST_API int sst_st_loss_fwd(const float* sr, const float* gt, float* loss, float
   return SST_OK;
 }
 
-SST_API int sst_st_loss_bwd(const float* sr, const float* gS, float* dsr, const float* scale_dev, float scale_host,
-                            int accumulate, int B, int H, int W, float sigma, float rho, void* stream) {
+SST_API int sst_st_loss_fwd(const float* sr, const float* gt, float* loss, float* gS, float* partials,
+                            unsigned* counter, int B, int H, int W, float sigma, float rho, int normalize,
+                            void* stream) {
+  return st_loss_fwd_impl(sr, gt, loss, gS, partials, counter, B, H, W, sigma, rho, normalize, StPix{nullptr, nullptr, -1}, stream);
+}
+
+// Structure-tensor loss + pixel criterion (pix_mode 0 = MSE, 1 = L1: reference config.py:88-90) in ONE launch: pix_loss[0] = the
+// criterion's mean over all B*3*H*W elements; pix_partials = as many floats as `partials`.
+SST_API int sst_st_pixel_loss_fwd(const float* sr, const float* gt, float* loss, float* gS, float* partials, unsigned* counter,
+                                  float* pix_loss, float* pix_partials, int pix_mode, int B, int H, int W, float sigma, float rho,
+                                  int normalize, void* stream) {
+  SST_REQUIRE(pix_loss && pix_partials && (pix_mode == 0 || pix_mode == 1), "sst_st_pixel_loss_fwd: bad pixel-criterion argument");
+  return st_loss_fwd_impl(sr, gt, loss, gS, partials, counter, B, H, W, sigma, rho, normalize, StPix{pix_loss, pix_partials, pix_mode},
+                          stream);
+}
+
+static int st_loss_bwd_impl(const float* sr, const float* gS, float* dsr, const float* scale_dev, float scale_host, int accumulate, int B,
+                            int H, int W, float sigma, float rho, const float* pix_gt, float pix_scale, int pix_mode, void* stream) {
   SST_REQUIRE(sr && gS && dsr, "sst_st_loss_bwd: null pointer");
   SST_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535, "sst_st_loss_bwd: bad shape");
   const int r1 = radius_of(sigma), r2 = radius_of(rho);
@@ -419,13 +471,28 @@ SST_API int sst_st_loss_bwd(const float* sr, const float* gS, float* dsr, const 
   const float s = scale_host / ((float)B * (float)H * (float)W);
   if (r1 == 2 && r2 == 8) {
     st_loss_bwd_kernel<2, 8><<<grid, NT, 0, sst_stream(stream)>>>(sr, gS, dsr, scale_dev, s, accumulate, B, H, W,
-                                                                    make_taps<2, 8>(sigma, rho));
+                                                                    make_taps<2, 8>(sigma, rho), pix_gt, pix_scale, pix_mode);
   } else if (r1 == 4 && r2 == 10) {
     st_loss_bwd_kernel<4, 10><<<grid, NT, 0, sst_stream(stream)>>>(sr, gS, dsr, scale_dev, s, accumulate, B, H, W,
-                                                                     make_taps<4, 10>(sigma, rho));
+                                                                     make_taps<4, 10>(sigma, rho), pix_gt, pix_scale, pix_mode);
   } else {
     return sst_set_error(SST_ERR_UNSUPPORTED, "sst_st_loss_bwd: (sigma,rho)=(%g,%g) not built", sigma, rho);
   }
   SST_LAUNCH_CHECK("st_loss_bwd_kernel");
   return SST_OK;
+}
+
+SST_API int sst_st_loss_bwd(const float* sr, const float* gS, float* dsr, const float* scale_dev, float scale_host,
+                            int accumulate, int B, int H, int W, float sigma, float rho, void* stream) {
+  return st_loss_bwd_impl(sr, gS, dsr, scale_dev, scale_host, accumulate, B, H, W, sigma, rho, nullptr, 0.f, 0, stream);
+}
+
+// ... and both gradients in one launch: dsr (+)= (scale_dev ? *scale_dev : 1) * (scale_host * d ST-loss / d sr + pix_weight * d pixel
+// criterion / d sr).
+SST_API int sst_st_pixel_loss_bwd(const float* sr, const float* gt, const float* gS, float* dsr, const float* scale_dev, float scale_host,
+                                  float pix_weight, int pix_mode, int accumulate, int B, int H, int W, float sigma, float rho,
+                                  void* stream) {
+  SST_REQUIRE(gt && (pix_mode == 0 || pix_mode == 1), "sst_st_pixel_loss_bwd: bad pixel-criterion argument");
+  return st_loss_bwd_impl(sr, gS, dsr, scale_dev, scale_host, accumulate, B, H, W, sigma, rho, gt,
+                          pix_weight / (3.f * (float)B * (float)H * (float)W), pix_mode, stream);
 }

@@ -23,6 +23,8 @@ SIGNATURES = {
     "sst_st_loss_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64)]),
     "sst_st_loss_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_int, P]),
     "sst_st_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "sst_st_pixel_loss_fwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
+    "sst_st_pixel_loss_bwd": (c_int, [P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     "sst_conv_packed_floats": (c_int64, [c_int, c_int, c_int]),
     "sst_conv_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "sst_conv_pack_multi": (c_int, [P, c_int, c_int, P]),

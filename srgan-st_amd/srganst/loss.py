@@ -8,6 +8,7 @@ ContentLossDiscriminator <- reference loss.py:231-289, in disc_loss.py (re-expor
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -116,6 +117,35 @@ class L1Loss(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
+FUSE_PIXEL_INTO_ST = os.environ.get("SST_FUSE_PIXEL_ST", "1") != "0"
+
+
+def _st_pixel_fwd(x, gt, sigma, rho, normalize, ws, mode):
+    """Structure-tensor loss and pixel criterion (mode 0 MSE / 1 L1) of (x, gt) in one launch -> (st_loss, pixel_loss, gS)."""
+    from . import ops
+    if x.dtype != torch.float32 or gt.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or x.shape != gt.shape:
+        raise _abi.HipPathError(f"StructureTensorLoss: expected fp32 [B,3,H,W] pairs, got {tuple(x.shape)} / {tuple(gt.shape)}")
+    B, _, H, W = x.shape
+    lib = _abi.lib()
+    n = ctypes.c_int64()
+    _abi.check(lib.sst_st_loss_workspace(B, H, W, ctypes.byref(n)), "sst_st_loss_workspace")
+    key = (x.device, B, H, W)
+    if ws.get("key") != key:
+        ws["key"] = key
+        ws["partials"] = torch.empty(n.value, device=x.device, dtype=torch.float32)
+        ws["counter"] = torch.zeros(1, device=x.device, dtype=torch.int32)
+    if ws.get("pix_partials") is None or ws["pix_partials"].numel() != n.value or ws["pix_partials"].device != x.device:
+        ws["pix_partials"] = torch.empty(n.value, device=x.device, dtype=torch.float32)
+    gS = torch.empty_like(x)
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    pix = torch.empty((), device=x.device, dtype=torch.float32)
+    args = (_abi.ptr(x), _abi.ptr(gt), _abi.ptr(loss), _abi.ptr(gS), _abi.ptr(ws["partials"]), _abi.ptr(ws["counter"]), _abi.ptr(pix),
+            _abi.ptr(ws["pix_partials"]), int(mode), B, H, W, sigma, rho, int(normalize))
+    _abi.check(lib.sst_st_pixel_loss_fwd(*args, _abi.stream_ptr()), "sst_st_pixel_loss_fwd")
+    ops._trace_hbm("st_loss_fwd_kernel", 2.0 * x.numel() * 4, lambda: lib.sst_st_pixel_loss_fwd(*args, _abi.stream_ptr()), x, gt, loss, gS, ws, pix)
+    return loss, pix, gS
+
+
 class _CriterionSumFn(torch.autograd.Function):
     """total = sum_i w_i * criterion_i(sr, gt) for HIP-path criterions, as ONE autograd node: the weighted values and the
     total come out of one tiny kernel, and the backward kernels of the terms accumulate into one d(sr) buffer with the
@@ -129,12 +159,28 @@ class _CriterionSumFn(torch.autograd.Function):
         sr, gt = sr.contiguous(), gt.contiguous()
         lib = _abi.lib()
         raw, saved = [], []
-        for i, t in enumerate(terms):
-            if isinstance(t, StructureTensorLoss):
-                raw.append(_StLossFn.forward(_Ctx(saved), sr, gt, float(t.sigma), float(t.rho), bool(t.normalize), t._ws))
-            else:
-                raw.append(ops.pixel_loss_fwd(sr, gt, 0 if isinstance(t, MSELoss) else 1, t._ws))
-                saved.append(None)
+        # one structure-tensor term + one pixel term (the step's usual pair): the pixel criterion rides along in the structure-tensor
+        # kernels - same reads of sr / gt, two launches less per step (forward and backward)
+        st_i = [i for i, t in enumerate(terms) if isinstance(t, StructureTensorLoss)]
+        px_i = [i for i, t in enumerate(terms) if isinstance(t, (MSELoss, L1Loss))]
+        ctx.fused_pair = None
+        if FUSE_PIXEL_INTO_ST and len(st_i) == 1 and len(px_i) == 1 and sr.dim() == 4 and sr.shape[1] == 3:
+            t = terms[st_i[0]]
+            mode = 0 if isinstance(terms[px_i[0]], MSELoss) else 1
+            st_loss, pix_loss, gS = _st_pixel_fwd(sr, gt, float(t.sigma), float(t.rho), bool(t.normalize), t._ws, mode)
+            raw, saved = [None] * len(terms), [None] * len(terms)
+            raw[st_i[0]], raw[px_i[0]], saved[st_i[0]] = st_loss, pix_loss, gS
+            ctx.fused_pair = (st_i[0], px_i[0], mode)
+            for i, t2 in enumerate(terms):
+                if raw[i] is None:
+                    raise _abi.HipPathError("criterion sum: unexpected term next to the fused pixel + structure-tensor pair")
+        else:
+            for i, t in enumerate(terms):
+                if isinstance(t, StructureTensorLoss):
+                    raw.append(_StLossFn.forward(_Ctx(saved), sr, gt, float(t.sigma), float(t.rho), bool(t.normalize), t._ws))
+                else:
+                    raw.append(ops.pixel_loss_fwd(sr, gt, 0 if isinstance(t, MSELoss) else 1, t._ws))
+                    saved.append(None)
         n = len(terms)
         total = torch.empty((), device=sr.device, dtype=torch.float32)
         weighted = torch.empty(n, device=sr.device, dtype=torch.float32)
@@ -154,6 +200,15 @@ class _CriterionSumFn(torch.autograd.Function):
         g = grad_total.contiguous().to(torch.float32)
         B, _, H, W = sr.shape
         dsr = torch.empty_like(sr)
+        if ctx.fused_pair is not None:
+            si, pi, mode = ctx.fused_pair
+            t = ctx.terms[si]
+            bargs = (_abi.ptr(sr), _abi.ptr(gt), _abi.ptr(ctx.gS[si]), _abi.ptr(dsr), _abi.ptr(g), ctx.weights[si], ctx.weights[pi], mode, 0,
+                     B, H, W, float(t.sigma), float(t.rho))
+            _abi.check(_abi.lib().sst_st_pixel_loss_bwd(*bargs, _abi.stream_ptr()), "sst_st_pixel_loss_bwd")
+            ops._trace_hbm("st_loss_bwd_kernel", 1.0 * sr.numel() * 4, lambda: _abi.lib().sst_st_pixel_loss_bwd(*bargs, _abi.stream_ptr()),
+                           sr, gt, ctx.gS[si], dsr, g)
+            return dsr, None, None, None, None
         for i, (t, w) in enumerate(zip(ctx.terms, ctx.weights)):
             if isinstance(t, StructureTensorLoss):
                 bargs = (_abi.ptr(sr), _abi.ptr(ctx.gS[i]), _abi.ptr(dsr), _abi.ptr(g), w, int(i > 0), B, H, W, float(t.sigma), float(t.rho))

@@ -50,6 +50,35 @@ def test_l1_inside_fused_criterion_sum():
     assert rel_err(ga.cpu(), gb.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("kind", ["mse", "l1"])
+@pytest.mark.parametrize("shape", [(16, 3, 96, 96), (2, 3, 41, 75), (8, 3, 192, 192)])
+def test_pixel_criterion_riding_in_the_structure_tensor_kernels(kind, shape, monkeypatch):
+    """Pixel + structure-tensor pair of the training step (train.py:129-140) as two launches in all (sst_st_pixel_loss_fwd / _bwd:
+    the pixel criterion rides along in the structure-tensor kernels) against the four-launch form (SST_FUSE_PIXEL_ST=0) and against
+    torch fp64 for the pixel part; either order of the terms, non-unit upstream gradient, ragged image sizes."""
+    from srganst import loss as sloss
+    from srganst.loss import L1Loss, MSELoss, StructureTensorLoss, criterion_sum
+    g = torch.Generator().manual_seed(sum(shape) + len(kind))
+    gt = torch.rand(*shape, generator=g)
+    x = (gt + 0.05 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    pix, st = (MSELoss() if kind == "mse" else L1Loss()), StructureTensorLoss()
+    xd, gtd = x.cuda(), gt.cuda()
+    for terms, w in (([pix, st], [1.0, 1.0 / 3.0]), ([st, pix], [0.25, 2.0])):
+        outs = []
+        for fuse in (True, False):
+            monkeypatch.setattr(sloss, "FUSE_PIXEL_INTO_ST", fuse)
+            xa = xd.clone().requires_grad_(True)
+            total, weighted = criterion_sum(xa, gtd, terms, w)
+            (ga,) = torch.autograd.grad(total * 0.7, xa)
+            outs.append((total.item(), weighted.cpu(), ga.cpu()))
+        (t1, w1, g1), (t0, w0, g0) = outs
+        assert abs(t1 - t0) <= 2e-6 * abs(t0) and torch.allclose(w1, w0, rtol=2e-6, atol=0)
+        assert rel_err(g1, g0) < 1e-6
+        pi = terms.index(pix)
+        ref = (F.mse_loss if kind == "mse" else F.l1_loss)(x.double(), gt.double()) * w[pi]
+        assert abs(w1[pi].item() - ref.item()) <= 1e-5 * abs(ref.item())
+
+
 def test_configs0_warmup_step_l1_vs_oracle():
     """BASELINE configs[0] on the HIP path: one warm-up iteration with the pixel-L1 criterion only, B = 4, 96 -> 24 px
     (reduced depth to keep the CPU oracle short): SR, loss, every gradient (fp64-truth rule) and the Adam-updated weights."""
