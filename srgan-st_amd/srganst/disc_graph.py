@@ -61,7 +61,7 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
         bump_counters = False
     sv = {"layers": []}
     wp, sv["wd"], sv["ws2"] = _packs(module, p, need_grad)
-    if training and bump_counters:
+    if training and bump_counters and not module.__dict__.get("_counters_external"):
         ops.flatten_bn_counters(module).add_(1)
     x3 = ops.transpose(x.contiguous(), to_nchw=False)
     h, scale, shift, act = x3, None, None, 0
@@ -105,7 +105,8 @@ def replay_running_stats(module, p, sv):
     per-tile partials, i.e. the very launch the forward would issue) and of num_batches_tracked.  engine.TrainEngine uses it for
     the discriminator step's D(sr.detach()) (train.py:158), which repeats the generator step's D(sr) (train.py:136) before any
     weight has changed."""
-    ops.flatten_bn_counters(module).add_(1)
+    if not module.__dict__.get("_counters_external"):
+        ops.flatten_bn_counters(module).add_(1)
     for rec in sv["layers"]:
         if rec["bi"] is None:
             continue

@@ -41,7 +41,7 @@ def _one(like):
     return o
 
 
-def _criterion_total(sr, gt, criterions, weights, adversarial=None):
+def _criterion_total(sr, gt, criterions, weights, adversarial=None, adv_logits=None, adv_label=None):
     """sum_name weight * criterion(sr, gt) as in the reference loops (train.py:129-140, warmup.py:79-86); the values come
     back per name (already weighted, detached).  HIP-path pixel / structure-tensor terms share one autograd node
     (loss.criterion_sum); "Adversarial" (through D) and any other criterion go through autograd term by term."""
@@ -53,8 +53,14 @@ def _criterion_total(sr, gt, criterions, weights, adversarial=None):
         total, weighted = criterion_sum(sr, gt, [criterions[n] for n in fused], [weights[n] for n in fused])
         for i, n in enumerate(fused):
             vals[n] = weighted[i]
+    from .loss import BCEWithLogitsLoss, adversarial_term
     for name, crit in criterions.items():
         if name in fused:
+            continue
+        if name == "Adversarial" and adversarial is not None and adv_logits is not None and total is not None and isinstance(crit, BCEWithLogitsLoss):
+            # total + w * BCE(D(sr), label) as ONE node: the scaling and the sum ride in the loss kernels (forward: one tiny launch
+            # instead of mul + add; backward: the weight is folded into the BCE gradient's scale)
+            total, vals[name] = adversarial_term(total, adv_logits(), crit, adv_label, weights[name])
             continue
         l = (adversarial(crit) if (name == "Adversarial" and adversarial is not None) else crit(sr, gt)) * weights[name]
         vals[name] = l.detach()
@@ -303,7 +309,8 @@ class TrainEngine:
         self.D.__dict__["_packs_fresh"] = False      # the generator step always packs D's current weights (also when captured)
         sr = self.G(self.lr)
         total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
-                                       adversarial=lambda crit: crit(self.D(sr), self.real))
+                                       adversarial=lambda crit: crit(self.D(sr), self.real),
+                                       adv_logits=lambda: self.D(sr), adv_label=self.real)
         total.backward(_one(total))
         self.sr = sr.detach()
         self.loss_values = vals
@@ -331,7 +338,8 @@ class TrainEngine:
         if early_pack:
             main.wait_stream(self._side_d)
         total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
-                                       adversarial=lambda crit: crit(self.D(sr), self.real))
+                                       adversarial=lambda crit: crit(self.D(sr), self.real),
+                                       adv_logits=lambda: self.D(sr), adv_label=self.real)
         self.D.__dict__["_keep_pass"] = False
         self.sr = sr.detach()
         self.loss_values = vals
@@ -501,6 +509,12 @@ class TrainEngine:
     # join (the generator's backward through D still reads D's weights).  Same kernels, same arguments, same order per tensor:
     # bit-identical to the sequential schedule.
     def _iter_gd(self):
+        try:
+            return self._iter_gd_body()
+        finally:
+            self.D.__dict__["_counters_external"] = False
+
+    def _iter_gd_body(self):
         cfg = self.config
         for p in self.D.parameters():
             p.requires_grad = False
@@ -508,6 +522,10 @@ class TrainEngine:
         self.D.__dict__["_packs_fresh"] = False
         self.D.__dict__["_keep_pass"], self.D.__dict__["_last_pass"] = True, None
         from . import disc_graph, ops
+        adv_d = "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS
+        # the batch counters of D's BatchNorms move by one per pass (run or replayed): ONE add per iteration instead of three
+        self.D.__dict__["_counters_external"] = True
+        ops.flatten_bn_counters(self.D).add_(3 if adv_d else 2)
         ops.debug_stamp(0)
         main = torch.cuda.current_stream()
         if self._side_d is None:
@@ -528,7 +546,8 @@ class TrainEngine:
             main.wait_stream(self._side_d)           # D(sr) below reads the packed weights
         ops.debug_stamp(1)
         total, vals = _criterion_total(sr, self.gt, cfg.MODEL.G_LOSS.CRITERIONS, cfg.MODEL.G_LOSS.CRITERION_WEIGHTS,
-                                       adversarial=lambda crit: crit(self.D(sr), self.real))
+                                       adversarial=lambda crit: crit(self.D(sr), self.real),
+                                       adv_logits=lambda: self.D(sr), adv_label=self.real)
         self.D.__dict__["_keep_pass"] = False
         self.sr = sr.detach()
         ops.debug_stamp(2)
@@ -561,6 +580,7 @@ class TrainEngine:
             launch()
         main.wait_stream(self._side_d)
         self._d_step()
+        self.D.__dict__["_counters_external"] = False
         ops.debug_stamp(9)
         return vals
 

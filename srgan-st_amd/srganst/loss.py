@@ -418,6 +418,42 @@ class _BceFn(torch.autograd.Function):
         return dl, None
 
 
+class _AdvTermFn(torch.autograd.Function):
+    """total + w * BCEWithLogits(logits, t) -> (new total, w * BCE): the generator's adversarial term (reference train.py:136-140:
+    `loss = criterion(D(sr), real) * weight; total += loss`) as one autograd node - one tiny launch for scaling + sum in the forward,
+    and the weight folded into the scale of the BCE gradient in the backward (no mul / add launches of autograd)."""
+
+    @staticmethod
+    def forward(ctx, total, logits, t, w):
+        from . import ops
+        logits = logits.contiguous()
+        raw, _ = ops.bce_logits(logits, t, want_loss=True)
+        out = torch.empty((), device=logits.device, dtype=torch.float32)
+        weighted = torch.empty(2, device=logits.device, dtype=torch.float32)
+        tot = total.contiguous()
+        ptrs = (ctypes.c_void_p * 2)(_abi.ptr(tot), _abi.ptr(raw))
+        wts = (ctypes.c_float * 2)(1.0, float(w))
+        _abi.check(_abi.lib().sst_weighted_sum(ptrs, wts, 2, _abi.ptr(out), _abi.ptr(weighted), _abi.stream_ptr()), "sst_weighted_sum")
+        ctx.save_for_backward(logits)
+        ctx.t, ctx.w = t, float(w)
+        ctx.mark_non_differentiable(weighted)
+        ctx.set_materialize_grads(False)
+        return out, weighted
+
+    @staticmethod
+    def backward(ctx, g, _gw):
+        from . import ops
+        (logits,) = ctx.saved_tensors
+        _, dl = ops.bce_logits(logits, ctx.t, want_loss=False, want_grad=True, scale_dev=g.contiguous(), scale_host=ctx.w)
+        return g, dl, None, None
+
+
+def adversarial_term(total, logits, crit, label, weight):
+    """-> (total + weight * crit(logits, label), weight * crit(...) detached) for crit = BCEWithLogitsLoss (see _AdvTermFn)."""
+    out, weighted = _AdvTermFn.apply(total, logits, crit.label_value(label), weight)
+    return out, weighted[1]
+
+
 class BCEWithLogitsLoss(nn.Module):
     """nn.BCEWithLogitsLoss() of reference config.py:71-73 / train.py:59.  The reference always calls it
     with a constant-filled label tensor (train.py:113-114: 0.9 or 0); the label value is read once on the
@@ -428,6 +464,9 @@ class BCEWithLogitsLoss(nn.Module):
         self._label_cache = {}
 
     def forward(self, logits, label):
+        return _BceFn.apply(logits, self.label_value(label))
+
+    def label_value(self, label):
         if isinstance(label, (int, float)):
             t = float(label)
         else:
@@ -439,7 +478,7 @@ class BCEWithLogitsLoss(nn.Module):
                     raise _abi.HipPathError("BCEWithLogitsLoss (HIP path): label tensor must be constant-filled "
                                             "(reference train.py:113-114 uses full([B,1], 0.9) / zeros)")
                 self._label_cache = {key: t}
-        return _BceFn.apply(logits, t)
+        return t
 
 
 from .vgg_loss import ContentLossVGG  # noqa: E402,F401  (reference loss.py:11)
