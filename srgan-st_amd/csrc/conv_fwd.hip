@@ -469,6 +469,93 @@ __global__ __launch_bounds__(CONV_NT) void conv3_c3in_kernel(const float* __rest
   }
 }
 
+// The 3-channel-input layer above on the matrix cores (round 2; W % 32 == 0, Cout == 64: the discriminator's first layer at 96 /
+// 192 px).  M = 64 output channels (two MFMA halves), N = 32 pixels of one row segment, K = (ky, kx, ci) = 27 run as 3 rows x 10
+// columns (the 10th column of a row has zero weights): lane (pixel, kk) reads the raw 3-channel patch in LDS at pixel*3 + kk plus
+// an immediate per K step - no im2col.  Weights come from LDS (staged once per workgroup, MFMA A layout), the 32 x 64 result goes
+// through LDS so that every store instruction writes 1 KB of contiguous output: the launch is bound by writing its output once
+// (37.7 MB at B = 16 / 96 px; a plain fill of that size takes 7.5 us on this chip, tools/hbm_probe.py).
+constexpr int C3F_ROW = 104;                  // floats per patch row in LDS (34 px x 3 ch = 102, + the 10th-column overrun)
+constexpr int C3F_OST = 68;                   // floats per pixel in the output staging (64 channels + pad)
+__global__ __launch_bounds__(CONV_NT) void conv3_c3in_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                  const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                                  int W, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float ost[4][32 * C3F_OST];    // per wave: patch rows first, then the output tile
+  __shared__ float wl[15 * 2 * 64];                                      // weights in A layout: [(ky, s)][h][lane]
+  constexpr int Cout = 64;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  // weights: K step (ky, s) holds columns j = 2s + kk of row ky (j = kx*3 + ci; j = 9: zero) for channel 32h + li
+  for (int i = tid; i < 15 * 2 * 64; i += CONV_NT) {
+    const int l = i & 63, h = (i >> 6) & 1, ks = i >> 7;
+    const int ky = ks / 5, j = 2 * (ks - ky * 5) + (l >> 5);
+    wl[i] = j < 9 ? wp[((size_t)(h * 9 + ky * 3 + j / 3) * 512 + (l & 31)) * 4 + j % 3] : 0.f;
+  }
+  float* const ps = ost[wave];
+  const int tpr = W >> 5;
+  // persistent: wave w of workgroup g walks tiles 4g + w, + 4 * gridDim.x, ...; the next tile's patch values are loaded into
+  // registers before the current tile's MFMAs and written to LDS behind its output stores
+  float pv[5];
+  auto load_patch = [&](int t) {
+    const int b = t / (H * tpr), rem = t - b * (H * tpr);
+    const int oy = rem / tpr, x0 = (rem - oy * tpr) << 5;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i = lane + 64 * u;
+      const int r = i / C3F_ROW, c = i - r * C3F_ROW;
+      const int iy = oy - 1 + r, fx = (x0 - 1) * 3 + c;
+      const bool ok = i < 3 * C3F_ROW + 8 && r < 3 && c < 102 && (unsigned)iy < (unsigned)H && (unsigned)fx < (unsigned)(W * 3);
+      pv[u] = ok ? x[((size_t)b * H + iy) * W * 3 + fx] : 0.f;
+    }
+  };
+  int t = blockIdx.x * 4 + wave;
+  if (t < ntiles) load_patch(t);
+  __syncthreads();                                         // weights staged
+  const float* const bl = ps + li * 3 + lh;
+  for (; t < ntiles; t += gridDim.x * 4) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i = lane + 64 * u;
+      if (i < 3 * C3F_ROW + 8) ps[i] = pv[u];
+    }
+    const int tn = t + gridDim.x * 4;
+    if (tn < ntiles) load_patch(tn);
+    f32x16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int s2 = 0; s2 < 5; ++s2) {
+        const float bv = bl[ky * C3F_ROW + 2 * s2];
+        const int ks = ky * 5 + s2;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(ks * 2 + 0) * 64 + lane], bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(ks * 2 + 1) * 64 + lane], bv, acc[1], 0, 0, 0);
+      }
+    // acc[h][r]: channel 32h + (r & 3) + 8 (r >> 2) + 4 lh of pixel li  ->  LDS [pixel][channel] (the patch is dead: LDS ops of a
+    // wave complete in order)  ->  rows of 256 B, 4 pixels per store instruction
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * h + 8 * q + 4 * lh;
+        f32x4 v = {acc[h][4 * q], acc[h][4 * q + 1], acc[h][4 * q + 2], acc[h][4 * q + 3]};
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+        *reinterpret_cast<f32x4*>(ps + li * C3F_OST + c) = v;
+      }
+    const int b = t / (H * tpr), rem = t - b * (H * tpr);
+    const int oy = rem / tpr, x0 = (rem - oy * tpr) << 5;
+    float* const yp = y + (((size_t)b * H + oy) * W + x0) * Cout;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = lane + 64 * i, px = idx >> 4, c4 = (idx & 15) * 4;
+      *reinterpret_cast<f32x4*>(yp + (size_t)px * Cout + c4) = *reinterpret_cast<const f32x4*>(ps + px * C3F_OST + c4);
+    }
+  }
+}
+
 // 3x3 / stride 1 / pad 1 conv from 64 channels to 3 (round 2): the DATA-GRADIENT of the discriminator's first layer (model.py:32) -
 // the last step of the generator's adversarial backward, d loss / d sr.  With 3 output channels the general kernel fills 3 of 32
 // MFMA columns (8 TFLOP/s, 62 us at 96 px).  Here kx is folded into N: P[x'][(tx, ci)] = sum_{ty, co} dY[y-1+ty][x'][co] *
@@ -792,6 +879,13 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   }
   if (ksize == 3 && stride == 1 && Cin == 3 && (Cout & 3) == 0 && CONV_NT % (Cout >> 2) == 0 && out_mode == OUT_NHWC && !in_scale &&
       in_act == ACT_NONE && !residual && !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !getenv("SST_NO_C3IN")) {
+    if ((W & 31) == 0 && Cout == 64 && !getenv("SST_NO_C3IN_MFMA")) {
+      const int ntiles = B * H * (W >> 5);
+      const int wgs = (ntiles + 3) / 4;
+      conv3_c3in_mfma_kernel<<<(unsigned)(wgs < 768 ? wgs : 768), CONV_NT, 0, st>>>(x, wp, bias, y, B, H, W, ntiles);
+      SST_LAUNCH_CHECK("conv3_c3in_mfma_kernel");
+      return SST_OK;
+    }
     const size_t lds = (size_t)3 * ((W + 2) * 3 + 1) * sizeof(float);
     if (lds <= 48 * 1024) {
       conv3_c3in_kernel<<<(unsigned)(B * H), CONV_NT, lds, st>>>(x, wp, bias, y, B, H, W, Cout);
@@ -827,7 +921,7 @@ SST_API const char* sst_conv_kernel_name(int B, int H, int W, int Cin, int Cout,
       (size_t)4 * ((W + 2 + 15) / 16) * 16 * 12 * sizeof(float) <= 60 * 1024)
     return "conv3_to3_kernel";       // (when called plain, as the data-gradient of a 3-channel-input layer is)
   if (ksize == 3 && stride == 1 && Cin == 3 && (Cout & 3) == 0 && CONV_NT % (Cout >> 2) == 0 && out_mode == OUT_NHWC && !fused_in)
-    return "conv3_c3in_kernel";      // (when called without input affine / activation / residual / statistics)
+    return ((W & 31) == 0 && Cout == 64 && !getenv("SST_NO_C3IN_MFMA")) ? "conv3_c3in_mfma_kernel" : "conv3_c3in_kernel";   // (when called without input affine / activation / residual / statistics)
   if (out_mode == OUT_NHWC) {
     const int R = sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride);
     if (R) return R * W / 16 == 9 ? "conv_band_kernel<9>" : "conv_band_kernel<3>";

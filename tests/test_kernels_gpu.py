@@ -563,12 +563,35 @@ def test_conv_fwd_three_channel_input(ops, case, monkeypatch):
     w = torch.randn(Cout, 3, 3, 3, generator=g) / 5.0
     b = torch.randn(Cout, generator=g)
     ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    monkeypatch.setenv("SST_NO_C3IN_MFMA", "1")           # the MFMA form of this layer has its own test
     assert _abi.lib().sst_conv_kernel_name(B, H, W, 3, Cout, 3, 1, 0, 0) == b"conv3_c3in_kernel"
     wp = ops.pack_conv(w.cuda())
     y = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, 3, 1, bias=b.cuda())[0]
     assert rel_err(nchw(y.cpu()), ref) < TOL
     monkeypatch.setenv("SST_NO_C3IN", "1")
     y2 = ops.conv_fwd(nhwc(x).cuda(), wp, Cout, 3, 1, bias=b.cuda())[0]
+    assert rel_err(y2.cpu(), y.cpu()) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 8, 32), (3, 5, 64), (1, 1, 32), (16, 96, 96), (2, 12, 96), (1, 7, 192)])
+def test_conv_fwd_three_channel_input_mfma_kernel(ops, case, monkeypatch):
+    """The discriminator's first layer (3 -> 64, bias, reference model.py:32) on the matrix cores (conv3_c3in_mfma_kernel: K = 3 rows
+    x 10 columns read straight from the raw patch, output written as whole 256-B pixel rows) vs fp64 conv2d and vs the VALU kernel,
+    with and without bias; image borders on all four sides, partial last workgroup."""
+    from srganst import _abi
+    B, H, W = case
+    g = torch.Generator().manual_seed(98)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) / 5.0
+    b = torch.randn(64, generator=g)
+    assert _abi.lib().sst_conv_kernel_name(B, H, W, 3, 64, 3, 1, 0, 0) == b"conv3_c3in_mfma_kernel"
+    wp = ops.pack_conv(w.cuda())
+    y = ops.conv_fwd(nhwc(x).cuda(), wp, 64, 3, 1, bias=b.cuda())[0]
+    assert rel_err(nchw(y.cpu()), F.conv2d(x.double(), w.double(), b.double(), 1, 1)) < TOL
+    y0 = ops.conv_fwd(nhwc(x).cuda(), wp, 64, 3, 1)[0]
+    assert rel_err(nchw(y0.cpu()), F.conv2d(x.double(), w.double(), None, 1, 1)) < TOL
+    monkeypatch.setenv("SST_NO_C3IN_MFMA", "1")
+    y2 = ops.conv_fwd(nhwc(x).cuda(), wp, 64, 3, 1, bias=b.cuda())[0]
     assert rel_err(y2.cpu(), y.cpu()) < TOL
 
 
