@@ -271,6 +271,55 @@ def timed_steps(eng, gt, lr, steps, warmup, world, device):
 STALL_EXIT = 3
 
 
+def launch_ranks(n, argv, limit_s=1500.0):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, torchrun-style environment,
+    rendezvous on 127.0.0.1) from a parent that never makes a GPU call and never re-execs, relay rank 0's JSON line, and return
+    non-zero if any rank does (the other ranks are then ended by their exact PIDs)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)     # drain the pipe while rank 0 runs
+    reader.start()
+    rc, t0 = 0, time.time()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    print(f"bench.py: rank {r} exited with {c}; ending the other ranks", file=sys.stderr, flush=True)
+        if live and (rc != 0 or time.time() - t0 > limit_s):
+            if rc == 0:
+                rc = STALL_EXIT
+                print(f"bench.py: ranks {sorted(live)} still running after {limit_s:.0f} s; ending them", file=sys.stderr, flush=True)
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        if live:
+            time.sleep(0.2)
+    reader.join(10)
+    sys.stdout.write("".join(lines))
+    sys.stdout.flush()
+    return rc
+
+
 def secondary_leg(primary, workload, rank, world, device, args, B, steps=40, warmup=6, limit_s=240.0, share_d_sr=False, key=None):
     """A second workload under the same timing protocol (the configs[1] SRResNet step next to the headline G+D+ST step).
     Every rank runs a watchdog: if the leg is not done after limit_s, rank 0 still prints the primary line (with the reason in
@@ -340,6 +389,9 @@ def main():
                          "ranks sharing one GPU: ranks then map onto the visible devices modulo their count)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # this process never touches the GPU: it only starts and watches the ranks
+
     from srganst import _abi, dist as sdist, ops as _ops
     _abi.lib()                                    # fail loudly if the HIP extension is missing
     _ops.OVERLAP = bool(args.overlap) and not args.no_overlap
@@ -347,8 +399,9 @@ def main():
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     rank, local, world = sdist.init_from_env(args.backend)
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        # a launcher that started a different number of ranks than --gpus says would record one job under another's name
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (rank {rank}): refusing to measure", file=sys.stderr, flush=True)
+        sys.exit(2)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -368,6 +421,8 @@ def main():
 
     out = None
     failed = False
+    comm = ({"backend": "rccl" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend(),
+             "ranks": torch.distributed.get_world_size()} if world > 1 else {"backend": None, "ranks": 1})
     if rank == 0:
         ms = el / args.steps * 1e3
         imgs = B * world * args.steps / el
@@ -377,7 +432,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl, "global_batch": B * world, "hr": args.hr, "lr": args.hr // 4,
-                          "parallelism": f"dp{world}", "hip_graph": graph_active, "d_update_interval": 1 if args.workload != "srresnet" else None,
+                          "parallelism": f"dp{world}", "comm": comm, "hip_graph": graph_active, "d_update_interval": 1 if args.workload != "srresnet" else None,
                           "d_sr_forward": ("shared with the generator step's D(sr) pass (same input and weights, bit-identical)"
                                            if d_sr_reused else ("run: all three discriminator forwards of train.py:136,155,158"
                                                                 if args.workload != "srresnet" else None)),

@@ -229,3 +229,21 @@ def test_dp_world2_overlapped_schedule_is_bit_identical():
         if "running" not in k and "num_batches" not in k:
             assert (res[True][0][k] == res[True][1][k]).all(), k
     assert not (res[True][0]["D.features.3.running_mean"] == res[True][1]["D.features.3.running_mean"]).all()
+
+
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (the form the driver's N = 1 command has): the parent starts two rank
+    processes itself (gloo carries the collectives: both ranks share the one test GPU) and relays rank 0's line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "4",
+                        "--no-roofline", "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["comm"] == {"backend": "gloo", "ranks": 2}
+    assert out["config"]["global_batch"] == 32 and out["config"]["hip_graph"] is True

@@ -1,5 +1,7 @@
 """CPU: host-side mirror of the reference interface - config surface, parameter trees, init RNG order,
 checkpoint key handling, metrics, bicubic LR synthesis - against the golden vectors and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -159,3 +161,26 @@ def test_patch_structure_tensor_matrices_match_oracle():
     J = torch.stack([(ix * ix) @ m[2].T, (iy * iy) @ m[2].T, (ix * iy) @ m[2].T], dim=1).view(50, 3, 3, 3)
     ref = ost.structure_tensor(gray.double(), 0.5, 2.0)
     assert float((J - ref).abs().max() / ref.abs().max()) < 1e-6
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_refuses_world_size_mismatch():
+    """A launcher that started one rank for `--gpus 2` must not get a one-GPU number labelled as two."""
+    p = _run_bench({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--steps", "1")
+    assert p.returncode == 2 and "refusing to measure" in p.stderr and not p.stdout.strip()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the CPU leg: on a GPU box tests/test_dp_gpu.py runs the launcher for real")
+def test_bench_launcher_propagates_a_failed_rank():
+    """Without a GPU every rank fails at device selection: the parent (which never touches the GPU) must start both ranks, end up
+    non-zero and print no JSON line."""
+    p = _run_bench({}, "--gpus", "2", "--steps", "1", "--no-roofline", "--no-cpu-baseline", "--no-secondary")
+    assert p.returncode != 0 and "exited with" in p.stderr and not p.stdout.strip()
