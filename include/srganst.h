@@ -23,6 +23,8 @@ const char* sst_arch(void);
 /* forget the HIP runtime's sticky last error (left behind by e.g. a failed stream capture) before going on in eager mode;
  * returns the pending code (0 = none) */
 int sst_clear_error(void);
+/* dev switches (SST_* environment variables) are read once, at their first use; this forgets them (tests that toggle a switch) */
+int sst_reload_env(void);
 
 /* ---- structure-tensor loss: loss.py:380-413 + utils.py:194-280 (sigma=.5, rho=2 default) -------
  * sr, gt, dsr: NCHW [B,3,H,W].  gS: saved [B,3,H,W].  partials: sst_st_loss_workspace() floats.
@@ -101,6 +103,18 @@ int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const float* bi
                       float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
                       const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
                       int H, int W, int Cin, int Cout, int ksize, int stride, void* stream);
+/* ... with COEFFICIENT GROUPS: several passes of the network over different inputs with the same weights - the discriminator step's
+ * D(gt) and D(sr.detach()), train.py:155-158 - run as ONE batch of B images in which every grp_images consecutive images form a
+ * pass with its own train-mode BatchNorm statistics.  The per-channel arrays in_scale / in_shift / epi_scale / epi_shift are then
+ * [B / grp_images][channels] (row = pass); stats / epi_partial tiles never straddle a pass (sst_conv_pipe_groups_ok: the pass
+ * boundary falls on a tile boundary of the tall image), so the tile rows of pass p are the p-th of B / grp_images equal consecutive
+ * ranges.  grp_images = 0 (or B): one row, the call above. */
+int sst_conv_pipe_groups_ok(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int grp_images);
+int sst_conv_pipe_fwd_grp(const float* x, const float* wp, float* y, const float* bias, const float* in_scale,
+                          const float* in_shift, const float* in_slope, float in_slope_const, int in_act, float* stats,
+                          float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
+                          const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
+                          int H, int W, int Cin, int Cout, int ksize, int stride, int grp_images, void* stream);
 /* stride-2 data-gradient (sst_conv_s2_dgrad below) on the pipelined kernel: the four parity classes of a block of class pixels in
  * one unit (they share the dY patch), the 9 (class, tap) pairs in the place of the 9 taps, one accumulator per class.  Even H, W;
  * Cout % 64 == 0, Cin % 32 == 0.  wp = the buffer of sst_conv_s2_dgrad_pack; ws = sst_conv_s2_dgrad_pipe_ws_floats floats (0: none).
@@ -169,6 +183,13 @@ int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, cons
                    const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
                    int B, int H, int W, int Cin, int Cout, int stride, int ksize, int accumulate,
                    void* stream);
+/* in_scale / in_shift [B / grp_images][Cin]: the images are grp_images-sized passes with their own BatchNorm coefficients (see
+ * sst_conv_pipe_fwd_grp), dW sums over all of them.  Taken by the all-taps tile kernel only (sst_conv_wgrad_groups_ok). */
+int sst_conv_wgrad_groups_ok(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int grp_images);
+int sst_conv_wgrad_grp(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
+                   const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
+                   int B, int H, int W, int Cin, int Cout, int stride, int ksize, int accumulate,
+                       int grp_images, void* stream);
 /* weight gradient of the two 9x9 convs with a 3-channel side (Generator.conv1 / conv3, model.py:101,127):
  * N = (kx, ch3) = 27 of 32 MFMA columns instead of 3.  kind 0 = conv3 (C->3), kind 1 = conv1 (3->C). */
 int sst_wgrad_c3_supported(int C, int ksize);
@@ -219,6 +240,11 @@ int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, int W, int
 int sst_bn_finalize(const float* stats, const float* cnt, int ntiles, int C, const float* gamma,
                     const float* beta, float* run_mean, float* run_var, float* mean, float* rstd,
                     float* scale, float* shift, float eps, float momentum, void* stream);
+/* `groups` passes batched as one tall image (see sst_conv_pipe_fwd_grp): stats / cnt hold ntiles tiles = groups equal consecutive
+ * ranges; mean / rstd / scale / shift are [groups][C]; the running statistics take one momentum step per group, in group order. */
+int sst_bn_finalize_grp(const float* stats, const float* cnt, int ntiles, int C, int groups, const float* gamma,
+                        const float* beta, float* run_mean, float* run_var, float* mean, float* rstd, float* scale,
+                        float* shift, float eps, float momentum, void* stream);
 int sst_bn_eval_affine(const float* gamma, const float* beta, const float* run_mean,
                        const float* run_var, float* scale, float* shift, int C, float eps, void* stream);
 int sst_bn_residual(const float* y, const float* scale, const float* shift, const float* res,
@@ -230,6 +256,18 @@ int sst_bwd_reduce(const float* g, const float* g2, const float* y, const float*
 int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean,
                      const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* cA,
                      float* cB, float* cC, float* dslope, int accumulate, void* stream);
+/* the three backward steps for `groups` passes batched as one tensor of groups * R rows (R rows per pass): scale / shift / mean / rstd /
+ * cA / cB / cC are [groups][C], partial is [groups][sst_bwd_reduce_blocks(R, C)][3][C], n = elements of ONE pass per channel;
+ * dgamma / dbeta (the passes share the parameters) sum over the passes in group order. */
+int sst_bwd_reduce_grp(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                       const float* slope, float slope_const, int act, float* partial, int64_t R, int C, int groups,
+                       void* stream);
+int sst_bwd_finalize_grp(const float* partial, int nblk, int C, float n, int groups, const float* mean, const float* rstd,
+                         const float* gamma, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int accumulate,
+                         void* stream);
+int sst_bwd_apply_grp(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                      const float* slope, float slope_const, int act, const float* cA, const float* cB, const float* cC,
+                      float* dy, int64_t R, int C, int groups, void* stream);
 /* channel-parallel also with dslope (scratch: (C+63)/64 floats, counter: one zeroed word, left zero) */
 int sst_bwd_finalize_wide(const float* partial, int nblk, int C, float n, const float* mean, const float* rstd,
                           const float* gamma, float* dgamma, float* dbeta, float* cA, float* cB, float* cC,
@@ -314,6 +352,9 @@ int sst_head_bwd(const float* h, const float* w, const float* dy, float* dh, flo
                  int N, int K, float slope, int accumulate, void* stream);
 int sst_flatten_act(const float* y, const float* scale, const float* shift, float slope, int act,
                     float* flat, int B, int HW, int C, void* stream);
+/* scale / shift [B / grp_images][C] (passes batched as one tensor); grp_images = 0: one row */
+int sst_flatten_act_grp(const float* y, const float* scale, const float* shift, float slope, int act,
+                        float* flat, int B, int HW, int C, int grp_images, void* stream);
 
 /* ---- optimizer: torch.optim.Adam(lr, betas, eps=1e-4) of train.py:62-75 / warmup.py:34-40 as ONE streaming pass over
  * flat parameter / gradient / moment buffers (n floats, n % 4 == 0).  steps: nsteps device floats, all incremented by

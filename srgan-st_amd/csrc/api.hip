@@ -13,6 +13,34 @@ int sst_set_error(int code, const char* fmt, ...) {
 }
 
 SST_API const char* sst_last_error(void) { return g_err; }
+
+// ---- dev switches, read once (common.h: sst_env)
+#include <cstdlib>
+#include <mutex>
+namespace {
+struct EnvEntry { char name[40]; char value[24]; bool set; };
+constexpr int ENV_MAX = 64;
+EnvEntry g_env[ENV_MAX];
+int g_env_n = 0;
+std::mutex g_env_mu;
+}  // namespace
+const char* sst_env(const char* name) {
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  for (int i = 0; i < g_env_n; ++i)
+    if (!strcmp(g_env[i].name, name)) return g_env[i].set ? g_env[i].value : nullptr;
+  const char* v = std::getenv(name);
+  if (g_env_n == ENV_MAX || strlen(name) >= sizeof(g_env[0].name)) return v;      // table full: uncached (never happens with the switches in tree)
+  EnvEntry& e = g_env[g_env_n++];
+  snprintf(e.name, sizeof(e.name), "%s", name);
+  e.set = v != nullptr;
+  snprintf(e.value, sizeof(e.value), "%s", v ? v : "");
+  return e.set ? e.value : nullptr;
+}
+SST_API int sst_reload_env(void) {
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  g_env_n = 0;
+  return SST_OK;
+}
 SST_API int sst_version(void) { return 100; }  // 0.1.0
 SST_API const char* sst_arch(void) { return "gfx950"; }
 // Forget the runtime's sticky "last error" (hipGetLastError reads AND clears it): a failed stream capture leaves one behind, and

@@ -18,14 +18,18 @@ constexpr int NT = 256;
 // Forward finalize: per-tile (sum, M2, count) partials of a conv output -> batch mean / rstd, the
 // fused affine (scale = gamma*rstd, shift = beta - mean*scale) and the running-stat update.
 // One workgroup per channel.
+// groups > 1: the tiles are `groups` equal consecutive ranges (several passes of the network batched as one tall image): each range
+// gets its own statistics / affine (outputs [groups][C]) and the running statistics take one momentum step per range, in order.
 __global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ cnt,
                                                          int ntiles, int C, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ run_mean,
                                                          float* __restrict__ run_var, float* __restrict__ mean_out,
                                                          float* __restrict__ rstd_out, float* __restrict__ scale,
-                                                         float* __restrict__ shift, float eps, float momentum) {
+                                                         float* __restrict__ shift, float eps, float momentum, int groups) {
   __shared__ float red[2][NT / 64];
   const int c = blockIdx.x;
+  for (int grp = 0; grp < groups; ++grp, stats += (size_t)ntiles * 2 * C, cnt += ntiles, mean_out += C, rstd_out += C, scale += C,
+           shift += C) {
   // One global round trip: a thread keeps its (up to KT) tiles' (sum, M2, count) in registers for both passes of Chan's
   // combination, and the two first-pass sums share one pair of barriers (this kernel is pure latency: ~1 us of work
   // behind a ~2.5 us launch, 33 times per step).
@@ -86,6 +90,8 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const float* __restrict
       run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
       run_var[c] = (1.f - momentum) * run_var[c] + momentum * (m2 / fmaxf(n - 1.f, 1.f));
     }
+  }
+  __syncthreads();          // red[] is reused by the next group
   }
 }
 
@@ -158,6 +164,8 @@ struct FinArgs {
   const float* mean; const float* rstd; const float* gamma;
   float* dgamma; float* dbeta; float* cA; float* cB; float* cC; float* dslope;
   float n; int accumulate;
+  int groups;        // > 1: nblk partial blocks PER GROUP, consecutive; mean / rstd / cA / cB / cC are [groups][C], n counts one group's
+                     // elements; dgamma / dbeta / dslope sum over the groups (group order)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -170,6 +178,18 @@ __global__ __launch_bounds__(NT) void bwd_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ shift, const float* __restrict__ slope_p,
                                                         float slope_c, int act, float* __restrict__ partial, int64_t R,
                                                         int C, int rows_per_block) {
+  // blockIdx.y = coefficient group (passes batched as one tall tensor): R rows per group, own scale / shift row, own partial blocks
+  {
+    const size_t go = (size_t)blockIdx.y * R * C;
+    g += go;
+    y += go;
+    if (g2) g2 += go;
+    if (scale) {
+      scale += blockIdx.y * C;
+      shift += blockIdx.y * C;
+    }
+    partial += (size_t)blockIdx.y * gridDim.x * 3 * C;
+  }
   // The three sums are signed and largely cancel (the BatchNorm gradients and, summed over channels, the scalar PReLU-slope
   // gradient): every accumulation is fp64 like the reference's CPU path (acc_type<float> = double), only the block partial is
   // rounded to fp32 once.  Step time unchanged (5.80 ms before and after, the kernel is bound by its loads).
@@ -256,13 +276,15 @@ __global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restr
   const int cstep = gridDim.x * 64;
   for (int cb = blockIdx.x * 64; cb < C; cb += cstep) {
     const int c = cb + cl;
+    float dg_tot = 0.f, db_tot = 0.f;
+    for (int grp = 0; grp < f.groups; ++grp) {
     // the partials are summed in fp64 and sum gz*(y - mean) = S1 - mean*S0 is evaluated in fp64: it cancels, and what fp32 loses
     // there comes back as a common-mode error of dy over the whole channel (see conv_band.hip, same arithmetic)
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
     if (c < C) {
 #pragma unroll 12
       for (int b = q; b < nblk; b += F2T / 64) {
-        const float* p = partial + (size_t)b * 3 * C + c;
+        const float* p = partial + ((size_t)grp * nblk + b) * 3 * C + c;
         d0 += (double)p[0];
         d1 += (double)p[C];
         d2 += (double)p[2 * C];
@@ -284,23 +306,33 @@ __global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restr
       const float s0 = (float)d0, s2 = (float)d2;
       al += s2;
       if (f.mean) {
-        const float mu = f.mean[c], rs = f.rstd[c], ga = f.gamma[c];
+        const int gc = grp * C + c;
+        const float mu = f.mean[gc], rs = f.rstd[gc], ga = f.gamma[c];
         const double sgh_d = (double)rs * (d1 - (double)mu * d0);
         const float sgh = (float)sgh_d;
         const float m1 = (float)(d0 / (double)f.n), m2 = (float)(sgh_d / (double)f.n);
-        if (f.accumulate) {
-          f.dgamma[c] += sgh;
-          f.dbeta[c] += s0;
-        } else {
-          f.dgamma[c] = sgh;
-          f.dbeta[c] = s0;
-        }
+        dg_tot = grp ? dg_tot + sgh : sgh;
+        db_tot = grp ? db_tot + s0 : s0;
         const float a = ga * rs;
-        f.cA[c] = a;
-        f.cB[c] = -a * rs * m2;
-        f.cC[c] = -a * m1 + a * rs * mu * m2;
+        f.cA[gc] = a;
+        f.cB[gc] = -a * rs * m2;
+        f.cC[gc] = -a * m1 + a * rs * mu * m2;
+      } else {
+        db_tot = grp ? db_tot + s0 : s0;
+      }
+    }
+    }   // groups
+    if (q == 0 && c < C) {
+      if (f.mean) {
+        if (f.accumulate) {
+          f.dgamma[c] += dg_tot;
+          f.dbeta[c] += db_tot;
+        } else {
+          f.dgamma[c] = dg_tot;
+          f.dbeta[c] = db_tot;
+        }
       } else if (f.dbeta) {
-        if (f.accumulate) f.dbeta[c] += s0; else f.dbeta[c] = s0;
+        if (f.accumulate) f.dbeta[c] += db_tot; else f.dbeta[c] = db_tot;
       }
     }
   }
@@ -328,6 +360,79 @@ __global__ __launch_bounds__(F2T) void bwd_finalize2_kernel(const float* __restr
   }
 }
 
+// The same finalize without the scalar slope gradient (every LeakyReLU layer: the whole discriminator), laid out for latency: a
+// workgroup owns 16 channels x 64 row lanes (thread: cl = tid & 15, q = tid >> 4), so a layer of C channels gets C/16 workgroups and a
+// thread walks nblk/64 partial rows instead of nblk/16 (the 64-channel layers ran ONE workgroup of 16 row lanes over up to 2,304
+// per-tile rows of a conv epilogue: 24-48 us of dependent loads for 0.6 MB).  The third partial (sum g*min(z,0)) is not read at all.
+constexpr int F3T = 1024;
+__global__ __launch_bounds__(F3T) void bwd_finalize3_kernel(const float* __restrict__ partial, int nblk, int C, FinArgs f) {
+  __shared__ double sm[2][F3T / 64][16];
+  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 16 + cl;
+  float dg_tot = 0.f, db_tot = 0.f;
+  for (int grp = 0; grp < f.groups; ++grp) {
+    double d0 = 0.0, d1 = 0.0;
+    if (c < C) {
+      const float* p = partial + ((size_t)grp * nblk + q) * 3 * C + c;
+      const size_t stride = (size_t)64 * 3 * C;
+#pragma unroll 4
+      for (int b = q; b < nblk; b += 64, p += stride) {
+        d0 += (double)p[0];
+        d1 += (double)p[C];
+      }
+    }
+    d0 += __shfl_xor(d0, 16, 64);
+    d1 += __shfl_xor(d1, 16, 64);
+    d0 += __shfl_xor(d0, 32, 64);
+    d1 += __shfl_xor(d1, 32, 64);
+    __syncthreads();                                   // the previous group's sums have been read
+    if (lane < 16) {
+      sm[0][wave][lane] = d0;
+      sm[1][wave][lane] = d1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+      d0 = d1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < F3T / 64; ++i) {
+        d0 += sm[0][i][cl];
+        d1 += sm[1][i][cl];
+      }
+      const float s0 = (float)d0;
+      if (f.mean) {
+        // sum gz*(y - mean) = S1 - mean*S0 in fp64: it cancels (see bwd_finalize2_kernel)
+        const int gc = grp * C + c;
+        const float mu = f.mean[gc], rs = f.rstd[gc], ga = f.gamma[c];
+        const double sgh_d = (double)rs * (d1 - (double)mu * d0);
+        const float sgh = (float)sgh_d;
+        const float m1 = (float)(d0 / (double)f.n), m2 = (float)(sgh_d / (double)f.n);
+        dg_tot = grp ? dg_tot + sgh : sgh;
+        db_tot = grp ? db_tot + s0 : s0;
+        const float a = ga * rs;
+        f.cA[gc] = a;
+        f.cB[gc] = -a * rs * m2;
+        f.cC[gc] = -a * m1 + a * rs * mu * m2;
+      } else {
+        db_tot = grp ? db_tot + s0 : s0;
+      }
+    }
+  }
+  if (threadIdx.x < 16 && c < C) {
+    if (f.mean) {
+      if (f.accumulate) {
+        f.dgamma[c] += dg_tot;
+        f.dbeta[c] += db_tot;
+      } else {
+        f.dgamma[c] = dg_tot;
+        f.dbeta[c] = db_tot;
+      }
+    } else if (f.dbeta) {
+      if (f.accumulate) f.dbeta[c] += db_tot; else f.dbeta[c] = db_tot;
+    }
+  }
+}
+
 // dy = cA*gz + cB*y + cC  (BatchNorm input gradient), or dy = gz when cA == null (activation only).
 __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ g2,
                                                        const float* __restrict__ y, const float* __restrict__ scale,
@@ -335,6 +440,23 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
                                                        float slope_c, int act, const float* __restrict__ cA,
                                                        const float* __restrict__ cB, const float* __restrict__ cC,
                                                        float* __restrict__ dy, int64_t R, int C, int uH, int uW) {
+  // blockIdx.y = coefficient group (passes batched as one tall tensor): R rows per group, own coefficient rows
+  {
+    const size_t go = (size_t)blockIdx.y * R * C;
+    g += go;
+    y += go;
+    dy += go;
+    if (g2) g2 += go;
+    if (scale) {
+      scale += blockIdx.y * C;
+      shift += blockIdx.y * C;
+    }
+    if (cA) {
+      cA += blockIdx.y * C;
+      cB += blockIdx.y * C;
+      cC += blockIdx.y * C;
+    }
+  }
   const int c4n = C >> 2;
   const int64_t total = R * c4n;
   const float slope = slope_p ? slope_p[0] : slope_c;
@@ -434,7 +556,22 @@ SST_API int sst_bn_finalize(const float* stats, const float* cnt, int ntiles, in
               "sst_bn_finalize: bad argument");
   SST_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "sst_bn_finalize: running stats must come together");
   bn_finalize_kernel<<<C, NT, 0, sst_stream(stream)>>>(stats, cnt, ntiles, C, gamma, beta, run_mean, run_var, mean, rstd,
-                                                        scale, shift, eps, momentum);
+                                                        scale, shift, eps, momentum, 1);
+  SST_LAUNCH_CHECK("bn_finalize_kernel");
+  return SST_OK;
+}
+
+// The same for `groups` passes batched as one tall image: stats / cnt hold ntiles tiles = groups equal consecutive ranges; mean / rstd /
+// scale / shift are [groups][C]; the running statistics take one momentum step per group, in group order (the order the reference runs
+// the passes in, train.py:155-158).
+SST_API int sst_bn_finalize_grp(const float* stats, const float* cnt, int ntiles, int C, int groups, const float* gamma,
+                                const float* beta, float* run_mean, float* run_var, float* mean, float* rstd, float* scale,
+                                float* shift, float eps, float momentum, void* stream) {
+  SST_REQUIRE(stats && cnt && gamma && beta && mean && rstd && scale && shift && ntiles > 0 && C > 0 && groups > 0 && ntiles % groups == 0,
+              "sst_bn_finalize_grp: bad argument (ntiles=%d groups=%d)", ntiles, groups);
+  SST_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "sst_bn_finalize_grp: running stats must come together");
+  bn_finalize_kernel<<<C, NT, 0, sst_stream(stream)>>>(stats, cnt, ntiles / groups, C, gamma, beta, run_mean, run_var, mean, rstd,
+                                                        scale, shift, eps, momentum, groups);
   SST_LAUNCH_CHECK("bn_finalize_kernel");
   return SST_OK;
 }
@@ -475,7 +612,7 @@ SST_API int sst_bwd_reduce_blocks(int64_t R, int C) {
 
 static int launch_bwd_reduce(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
                              const float* slope, float slope_const, int act, float* partial, int64_t R, int C,
-                             void* stream) {
+                             void* stream, int groups = 1) {
   SST_REQUIRE(g && y && partial && R > 0 && C >= 4 && (C & 3) == 0 && C <= 1024, "sst_bwd_reduce: bad argument (C=%d)", C);
   SST_REQUIRE(NT % (C / 4) == 0 || C / 4 > NT, "sst_bwd_reduce: C/4 must divide %d", NT);
   SST_REQUIRE(C / 4 <= NT, "sst_bwd_reduce: C too large");
@@ -483,7 +620,7 @@ static int launch_bwd_reduce(const float* g, const float* g2, const float* y, co
   const int rpb = (int)((R + nblk - 1) / nblk);
   const int rowlanes = NT / (C / 4);
   const size_t smem = (size_t)rowlanes * 3 * C * sizeof(double);
-  bwd_reduce_kernel<<<nblk, NT, smem, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, rpb);
+  bwd_reduce_kernel<<<dim3(nblk, groups), NT, smem, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, rpb);
   SST_LAUNCH_CHECK("bwd_reduce_kernel");
   return SST_OK;
 }
@@ -494,13 +631,45 @@ SST_API int sst_bwd_reduce(const float* g, const float* g2, const float* y, cons
   return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, stream);
 }
 
+// ---- the same three steps for `groups` passes batched as one tall tensor [groups * R rows][C] (R rows per group): scale / shift / mean /
+// rstd / cA / cB / cC are [groups][C] (each pass has its own batch statistics), partial is [groups][sst_bwd_reduce_blocks(R, C)][3][C],
+// n counts ONE group's elements per channel; dgamma / dbeta (parameters are shared by the passes) sum over the groups.
+SST_API int sst_bwd_reduce_grp(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                               const float* slope, float slope_const, int act, float* partial, int64_t R, int C, int groups,
+                               void* stream) {
+  SST_REQUIRE(groups > 0 && groups <= 65535, "sst_bwd_reduce_grp: bad group count %d", groups);
+  return launch_bwd_reduce(g, g2, y, scale, shift, slope, slope_const, act, partial, R, C, stream, groups);
+}
+
+SST_API int sst_bwd_finalize_grp(const float* partial, int nblk, int C, float n, int groups, const float* mean, const float* rstd,
+                                 const float* gamma, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int accumulate,
+                                 void* stream) {
+  SST_REQUIRE(partial && nblk > 0 && C > 0 && groups > 0, "sst_bwd_finalize_grp: bad argument");
+  SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize_grp: BN mode needs all BN pointers");
+  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, nullptr, n, accumulate, groups};
+  bwd_finalize3_kernel<<<(C + 15) / 16, F3T, 0, sst_stream(stream)>>>(partial, nblk, C, fin);
+  SST_LAUNCH_CHECK("bwd_finalize_kernel (groups)");
+  return SST_OK;
+}
+
+SST_API int sst_bwd_apply_grp(const float* g, const float* g2, const float* y, const float* scale, const float* shift,
+                              const float* slope, float slope_const, int act, const float* cA, const float* cB, const float* cC,
+                              float* dy, int64_t R, int C, int groups, void* stream) {
+  SST_REQUIRE(g && y && dy && R > 0 && C > 0 && (C & 3) == 0 && groups > 0 && groups <= 65535, "sst_bwd_apply_grp: bad argument");
+  bwd_apply_kernel<<<dim3(grid_for(R * (C / 4)), groups), NT, 0, sst_stream(stream)>>>(g, g2, y, scale, shift, slope, slope_const, act,
+                                                                                      cA, cB, cC, dy, R, C, 0, 0);
+  SST_LAUNCH_CHECK("bwd_apply_kernel (groups)");
+  return SST_OK;
+}
+
 SST_API int sst_bwd_finalize(const float* partial, int nblk, int C, float n, const float* mean, const float* rstd,
                              const float* gamma, float* dgamma, float* dbeta, float* cA, float* cB, float* cC,
                              float* dslope, int accumulate, void* stream) {
   SST_REQUIRE(partial && nblk > 0 && C > 0, "sst_bwd_finalize: bad argument");
   SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize: BN mode needs all BN pointers");
-  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
-  bwd_finalize2_kernel<<<dslope ? 1 : (C + 63) / 64, F2T, 0, sst_stream(stream)>>>(partial, nblk, C, fin, nullptr, nullptr);
+  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate, 1};
+  if (dslope) bwd_finalize2_kernel<<<1, F2T, 0, sst_stream(stream)>>>(partial, nblk, C, fin, nullptr, nullptr);
+  else bwd_finalize3_kernel<<<(C + 15) / 16, F3T, 0, sst_stream(stream)>>>(partial, nblk, C, fin);
   SST_LAUNCH_CHECK("bwd_finalize_kernel");
   return SST_OK;
 }
@@ -512,7 +681,7 @@ SST_API int sst_bwd_finalize_wide(const float* partial, int nblk, int C, float n
                                   float* dslope, int accumulate, float* scratch, unsigned* counter, void* stream) {
   SST_REQUIRE(partial && nblk > 0 && C > 0 && scratch && counter, "sst_bwd_finalize_wide: bad argument");
   SST_REQUIRE(!mean || (rstd && gamma && dgamma && dbeta && cA && cB && cC), "sst_bwd_finalize_wide: BN mode needs all BN pointers");
-  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate};
+  FinArgs fin = {mean, rstd, gamma, dgamma, dbeta, cA, cB, cC, dslope, n, accumulate, 1};
   bwd_finalize2_kernel<<<(C + 63) / 64, F2T, 0, sst_stream(stream)>>>(partial, nblk, C, fin, scratch, counter);
   SST_LAUNCH_CHECK("bwd_finalize_kernel (wide)");
   return SST_OK;

@@ -28,6 +28,11 @@ int sst_set_error(int code, const char* fmt, ...);
     if (e_ != hipSuccess) return sst_set_error(SST_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
+// Dev switches (SST_* environment variables): each is read from the environment ONCE, at its first use, and served from a table
+// afterwards, so that a shape query (slab / workspace size) and the launch it sizes always see the same value; sst_reload_env()
+// forgets the table (tests that toggle a switch call it).  Returns the value or nullptr (unset).
+const char* sst_env(const char* name);
+
 static inline hipStream_t sst_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- device helpers

@@ -487,7 +487,7 @@ inline size_t band_lds_bytes(int R, int W, int NB) {
 int sst_conv_band_rows(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
   if (ksize != 3 || stride != 1 || !band_eligible(Cout, Cin, 9) || W < 8) return 0;
   int want = 3;   // measured on the bench step: 768 bands of 48 px (3 workgroups per CU) beat 256 bands of 144 px by 3.6 %
-  if (const char* e = getenv("SST_CONV_BAND")) {
+  if (const char* e = sst_env("SST_CONV_BAND")) {
     want = atoi(e);
     if (want == 0) return 0;
   }

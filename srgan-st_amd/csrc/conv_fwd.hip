@@ -35,7 +35,7 @@ constexpr int BIG_MIN_TILES = 2048;   // measured (tools/ablate_big.py): +9 % at
 inline bool use_big_tiles(const Conv3Args& a, int ksize) {
   if (ksize != 3 || a.Cout < 64 || a.in2 || a.side_out) return false;
   if (a.out_mode != OUT_NHWC && a.out_mode != OUT_SHUFFLE && a.out_mode != OUT_STRIDE2) return false;
-  if (const char* e = getenv("SST_CONV_BIG")) return atoi(e) != 0;       // dev override
+  if (const char* e = sst_env("SST_CONV_BIG")) return atoi(e) != 0;       // dev override
   const long tiles = (long)a.B * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) * ((a.Cout + 63) / 64);
   return tiles >= BIG_MIN_TILES;
 }
@@ -868,7 +868,7 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   const size_t extra_lds = (size_t)(dbg_bits >> 4) * 1024;   // dev knob: pad LDS to cap workgroups per CU
   a.dbg = dbg_bits & 15;
   if (ksize == 3 && stride == 1 && Cin == 64 && Cout == 3 && out_mode == OUT_NHWC && !bias && !in_scale && in_act == ACT_NONE && !residual &&
-      !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !getenv("SST_NO_TO3")) {
+      !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !sst_env("SST_NO_TO3")) {
     const int nmt = (W + 2 + 15) / 16;
     const size_t lds = (size_t)4 * nmt * 16 * 12 * sizeof(float);
     if (lds <= 60 * 1024) {
@@ -878,8 +878,8 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
     }
   }
   if (ksize == 3 && stride == 1 && Cin == 3 && (Cout & 3) == 0 && CONV_NT % (Cout >> 2) == 0 && out_mode == OUT_NHWC && !in_scale &&
-      in_act == ACT_NONE && !residual && !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !getenv("SST_NO_C3IN")) {
-    if ((W & 31) == 0 && Cout == 64 && !getenv("SST_NO_C3IN_MFMA")) {
+      in_act == ACT_NONE && !residual && !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !sst_env("SST_NO_C3IN")) {
+    if ((W & 31) == 0 && Cout == 64 && !sst_env("SST_NO_C3IN_MFMA")) {
       const int ntiles = B * H * (W >> 5);
       const int wgs = (ntiles + 3) / 4;
       conv3_c3in_mfma_kernel<<<(unsigned)(wgs < 768 ? wgs : 768), CONV_NT, 0, st>>>(x, wp, bias, y, B, H, W, ntiles);
@@ -917,11 +917,11 @@ SST_API const char* sst_conv_kernel_name(int B, int H, int W, int Cin, int Cout,
   a.Ho = (H + 2 * p - ksize) / stride + 1;
   a.Wo = (W + 2 * p - ksize) / stride + 1;
   a.in2 = fused_in ? reinterpret_cast<const float*>(1) : nullptr;
-  if (ksize == 3 && stride == 1 && Cin == 64 && Cout == 3 && out_mode == OUT_NHWC && !fused_in && !getenv("SST_NO_TO3") &&
+  if (ksize == 3 && stride == 1 && Cin == 64 && Cout == 3 && out_mode == OUT_NHWC && !fused_in && !sst_env("SST_NO_TO3") &&
       (size_t)4 * ((W + 2 + 15) / 16) * 16 * 12 * sizeof(float) <= 60 * 1024)
     return "conv3_to3_kernel";       // (when called plain, as the data-gradient of a 3-channel-input layer is)
   if (ksize == 3 && stride == 1 && Cin == 3 && (Cout & 3) == 0 && CONV_NT % (Cout >> 2) == 0 && out_mode == OUT_NHWC && !fused_in)
-    return ((W & 31) == 0 && Cout == 64 && !getenv("SST_NO_C3IN_MFMA")) ? "conv3_c3in_mfma_kernel" : "conv3_c3in_kernel";   // (when called without input affine / activation / residual / statistics)
+    return ((W & 31) == 0 && Cout == 64 && !sst_env("SST_NO_C3IN_MFMA")) ? "conv3_c3in_mfma_kernel" : "conv3_c3in_kernel";   // (when called without input affine / activation / residual / statistics)
   if (out_mode == OUT_NHWC) {
     const int R = sst_conv_band_rows(B, H, W, Cin, Cout, ksize, stride);
     if (R) return R * W / 16 == 9 ? "conv_band_kernel<9>" : "conv_band_kernel<3>";
@@ -1089,7 +1089,7 @@ static int conv_s2_dgrad_impl(const float* dy, const float* wp, float* dx, int B
     a.B = B; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = Cin;
     a.ksy = a.ksx = 1; a.pad_y = a.pad_x = 0; a.sub_y = a.sub_x = 0; a.Ho = a.Wo = 0; a.Hy = H; a.Wy = W;
     S2Classes c;
-    bool ok = !getenv("SST_S2_SPLIT") || f;
+    bool ok = !sst_env("SST_S2_SPLIT") || f;
     int max_tiles = 0, tbase = 0;
     for (int cls = 0; cls < 4; ++cls) {
       const int py = cls >> 1, px = cls & 1;
@@ -1105,7 +1105,7 @@ static int conv_s2_dgrad_impl(const float* dy, const float* wp, float* dx, int B
       if (!f && c.tiles[cls] && use_big_tiles(t, 3)) ok = false;
       max_tiles = c.tiles[cls] > max_tiles ? c.tiles[cls] : max_tiles;
     }
-    static const bool s2d4 = !(getenv("SST_S2DGRAD4") && atoi(getenv("SST_S2DGRAD4")) == 0);
+    static const bool s2d4 = !(sst_env("SST_S2DGRAD4") && atoi(sst_env("SST_S2DGRAD4")) == 0);
     if (ok && s2d4 && !(H & 1) && !(W & 1) && !(Cout & 3) && !(Cin & 3)) {
       a.Ho = c.nh[0]; a.Wo = c.nw[0];
       dim3 grid((unsigned)c.tiles[0], (Cin + 31) / 32);
@@ -1153,7 +1153,7 @@ static int conv_s2_dgrad_impl(const float* dy, const float* wp, float* dx, int B
 // spelling): the merged-classes kernel for even H, W with channel counts that are multiples of 4, else the per-class launch.
 SST_API const char* sst_conv_s2_dgrad_kernel_name(int B, int H, int W, int Cin, int Cout, int fused) {
   (void)B;
-  const bool off = getenv("SST_S2DGRAD4") && atoi(getenv("SST_S2DGRAD4")) == 0;
+  const bool off = sst_env("SST_S2DGRAD4") && atoi(sst_env("SST_S2DGRAD4")) == 0;
   if (!off && !(H & 1) && !(W & 1) && !(Cout & 3) && !(Cin & 3)) return fused ? "conv_s2dgrad4_kernel<true>" : "conv_s2dgrad4_kernel<false>";
   return "conv_s2dgrad_kernel";
 }

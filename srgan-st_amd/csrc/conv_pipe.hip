@@ -47,7 +47,10 @@ struct PipeArgs {
   int B, H, W, Cin, Cout, Ho, Wo;
   int R;                    // B*Ho: rows of the tall output image
   int tiles_x, n_mt, nfc, total_tiles, ncb, ksplit, cb_per, units;
-  int dbg;
+  int gB, grows;            // coefficient groups: images per group (0 = one group) and rows of the tall output image per group.  The
+                            // per-channel arrays (in_scale / in_shift, epi_scale / epi_shift) are then [B / gB][channels]: every group
+                            // of gB consecutive images carries the BatchNorm coefficients of its own pass (several discriminator
+                            // passes - D(gt), D(sr) - batched as one tall image, train.py:155-158); tiles never straddle a group
 };
 
 // MODE 0: 3x3 conv (pad 1).  MODE 1: data-gradient of a 3x3 / stride-2 / pad-1 conv - the four parity classes of an 8x4 (TW x 32/TW)
@@ -74,6 +77,7 @@ constexpr int S2D_TAP[9] = {0, 0, 1, 0, 1, 0, 1, 2, 3};
 // one stage = one 64-channel block of one tile's input patch (+ the matching weight block)
 struct Stage {
   int b0, rem0, ix0, c0;       // image / virtual row inside it of patch row 0, first patch column, first channel
+  int gin;                     // float offset of the tile's coefficient group in in_scale / in_shift
   const float* w;              // this wave's weight pointer for the block (wave-uniform: + wave*512 floats; lanes add lane*16 B)
 };
 
@@ -149,8 +153,9 @@ __device__ __forceinline__ void pipe_epilogue(const PipeArgs& a, float v[4], int
     f32x4 yv = {0.f, 0.f, 0.f, 0.f}, es = {1.f, 1.f, 1.f, 1.f}, eh = {0.f, 0.f, 0.f, 0.f};
     if (pix_ok) yv = *reinterpret_cast<const f32x4*>(a.epi_y + obase);
     if (a.epi_scale) {
-      es = *reinterpret_cast<const f32x4*>(a.epi_scale + c0);
-      eh = *reinterpret_cast<const f32x4*>(a.epi_shift + c0);
+      const int ge = a.gB ? (r0 / a.grows) * a.Cout : 0;          // the tile's coefficient group (wave-uniform)
+      es = *reinterpret_cast<const f32x4*>(a.epi_scale + ge + c0);
+      eh = *reinterpret_cast<const f32x4*>(a.epi_shift + ge + c0);
     }
     f32x4 q[3];
 #pragma unroll
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
     s.rem0 = oy0_ * S;
     s.ix0 = ox0_ * S - (MODE ? 0 : 1);
     s.c0 = cb_ * CB;
+    s.gin = a.gB ? (b0_ / a.gB) * a.Cin : 0;
     s.w = a.wp + ((size_t)(nf_ * a.ncb + cb_) * 9 * 8) * 256 + wave * 512;
     return s;
   };
@@ -265,12 +271,11 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
         okmask |= ok ? (1u << u) : 0u;
       }
     }
-    const unsigned coff = (unsigned)(a.in_scale ? s.c0 + c4 : c4) * 4u;
+    const unsigned coff = (unsigned)(a.in_scale ? s.gin + s.c0 + c4 : c4) * 4u;
     PIPE_GLOAD(ssc, coff, sc_base);
     PIPE_GLOAD(ssh, coff, sh_base);
   };
   auto stage_store = [&]() {
-    if (a.dbg & 1) return;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int p = p0 + 16 * u;
@@ -373,11 +378,7 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (unit_end && (a.dbg & 2)) {
-      if (acc[0][0] == 12345.f) a.y[0] = acc[0][0];
-      if (!more) return;
-      a_base = lane_base(n_oy0);
-    } else if (unit_end) {
+    if (unit_end) {
       // ---- the 4 waves' K-partials -> LDS (NPAIR accumulators per round); afterwards wave w owns channels 8w .. 8w+7 of the
       // tile for all 32 pixels
       const int cl = 8 * wave + 4 * lh;    // first of this lane's 4 channels inside the 32-channel block
@@ -493,13 +494,28 @@ SST_API int64_t sst_conv_pipe_ws_floats(int B, int H, int W, int Cin, int Cout, 
   return (pl.tw && pl.ksplit > 1) ? (int64_t)pl.ksplit * pl.n_mt * pl.nfc * 1024 : 0;
 }
 
-SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const float* bias, const float* in_scale,
-                              const float* in_shift, const float* in_slope, float in_slope_const, int in_act, float* stats,
-                              float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
-                              const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
-                              int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+// Can a batch of B images be run with per-group coefficients (groups of grp_images consecutive images)?  The group boundary must fall
+// on a tile boundary of the tall image.
+SST_API int sst_conv_pipe_groups_ok(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int grp_images) {
+  const PipePlan pl = pipe_plan(B, H, W, Cin, Cout, ksize, stride);
+  if (!pl.tw || grp_images <= 0 || B % grp_images) return 0;
+  const int Ho = (H - 1) / stride + 1;
+  return (grp_images * Ho) % (32 / pl.tw) == 0;
+}
+
+// grp_images > 0: the per-channel coefficient arrays (in_scale / in_shift, epi_scale / epi_shift) are [B / grp_images][channels],
+// images b*grp_images .. (b+1)*grp_images - 1 use row b (several passes of the network batched as one tall image, each with the
+// BatchNorm coefficients of its own batch statistics).  0: one row for the whole batch.
+SST_API int sst_conv_pipe_fwd_grp(const float* x, const float* wp, float* y, const float* bias, const float* in_scale,
+                                  const float* in_shift, const float* in_slope, float in_slope_const, int in_act, float* stats,
+                                  float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
+                                  const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
+                                  int H, int W, int Cin, int Cout, int ksize, int stride, int grp_images, void* stream) {
   SST_REQUIRE(x && wp && y, "sst_conv_pipe_fwd: null pointer");
   const PipePlan pl = pipe_plan(B, H, W, Cin, Cout, ksize, stride);
+  SST_REQUIRE(grp_images == 0 || grp_images == B || sst_conv_pipe_groups_ok(B, H, W, Cin, Cout, ksize, stride, grp_images),
+              "sst_conv_pipe_fwd: coefficient groups of %d images do not end on tile boundaries (B=%d H=%d W=%d stride=%d)", grp_images, B,
+              H, W, stride);
   SST_REQUIRE(pl.tw, "sst_conv_pipe_fwd: shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d stride=%d is not taken by the pipelined kernel", B,
               H, W, Cin, Cout, ksize, stride);
   SST_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sst_conv_pipe_fwd: in_scale/in_shift must come together");
@@ -517,9 +533,10 @@ SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const f
   a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.R = B * a.Ho;
   a.tiles_x = pl.tiles_x; a.n_mt = pl.n_mt; a.nfc = pl.nfc; a.total_tiles = pl.n_mt * pl.nfc; a.ncb = pl.ncb;
   a.ksplit = pl.ksplit; a.cb_per = pl.ncb / pl.ksplit; a.units = a.total_tiles * pl.ksplit;
-  a.dbg = getenv("SST_PIPE_DBG") ? atoi(getenv("SST_PIPE_DBG")) : 0;     // ablation bits (tools/ablate_pipe.py): 1 no LDS staging writes, 2 no epilogue
+  a.gB = (grp_images > 0 && grp_images < B) ? grp_images : 0;
+  a.grows = a.gB * a.Ho;
   int wg_per_cu = stride == 1 ? 3 : 2;                 // = the kernels' launch bounds (register-limited)
-  if (const char* e = getenv("SST_PIPE_GPC")) {        // dev: fewer resident workgroups leave room for kernels of other streams
+  if (const char* e = sst_env("SST_PIPE_GPC")) {        // dev: fewer resident workgroups leave room for kernels of other streams
     const int v = atoi(e);
     if (v >= 1 && v < wg_per_cu) wg_per_cu = v;
   }
@@ -542,6 +559,15 @@ SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const f
   }
 #undef SST_PIPE_LAUNCH
   return SST_OK;
+}
+
+SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const float* bias, const float* in_scale,
+                              const float* in_shift, const float* in_slope, float in_slope_const, int in_act, float* stats,
+                              float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
+                              const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
+                              int H, int W, int Cin, int Cout, int ksize, int stride, void* stream) {
+  return sst_conv_pipe_fwd_grp(x, wp, y, bias, in_scale, in_shift, in_slope, in_slope_const, in_act, stats, stats_cnt, epi_y, epi_scale,
+                               epi_shift, epi_slope, epi_slope_const, epi_act, epi_partial, ws, B, H, W, Cin, Cout, ksize, stride, 0, stream);
 }
 
 // ---- stride-2 data-gradient on the pipelined kernel (MODE 1).  dx [B,H,W,Cin] = conv_transpose(dy [B,H/2,W/2,Cout]) for
@@ -607,7 +633,7 @@ SST_API int sst_conv_s2_dgrad_pipe_bwdstats(const float* dy, const float* wp, fl
   a.Ho = a.H; a.Wo = a.W; a.R = B * a.Ho;
   a.tiles_x = pl.tiles_x; a.n_mt = pl.n_mt; a.nfc = pl.nfc; a.total_tiles = pl.n_mt * pl.nfc; a.ncb = pl.ncb;
   a.ksplit = pl.ksplit; a.cb_per = pl.ncb / pl.ksplit; a.units = a.total_tiles * pl.ksplit;
-  a.dbg = 0;
+  a.gB = a.grows = 0;                      // the data-gradient's optional epilogue partials take one coefficient row
   const int grid = a.units < 2 * PIPE_CUS ? a.units : 2 * PIPE_CUS;
   hipStream_t st = sst_stream(stream);
 #define SST_S2D_LAUNCH(TW_)                                                                       \

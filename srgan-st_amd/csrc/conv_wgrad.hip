@@ -548,7 +548,7 @@ __global__ __launch_bounds__(1024) void c3m_reduce_kernel(const float* __restric
     *d = accumulate ? *d + t : t;
   }
 }
-inline bool k3c3_mfma_applies(int W, int Cout) { return (W & 31) == 0 && Cout == 64 && !getenv("SST_WGRAD_NO_K3C3_MFMA"); }
+inline bool k3c3_mfma_applies(int W, int Cout) { return (W & 31) == 0 && Cout == 64 && !sst_env("SST_WGRAD_NO_K3C3_MFMA"); }
 inline int k3c3_mfma_chunks(int B, int H, int W) { return (B * H * (W >> 5) + 3) / 4; }
 
 inline bool k3c3_applies(int Cin, int ksize, int stride, const float* in_scale, int in_act) {
@@ -560,17 +560,17 @@ struct WgBandPlan { int R, bpc, nchunk, nbands; size_t lds; };
 inline WgBandPlan wgrad_band_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int njobs) {
   WgBandPlan best{0, 0, 0, 0, 0};
   if (ksize != 3 || stride != 1 || (Cin & 63) || (Cout & 63) || (W & 3) || W < 4) return best;
-  if (const char* e = getenv("SST_WGRAD_BAND")) {
+  if (const char* e = sst_env("SST_WGRAD_BAND")) {
     if (atoi(e) == 0) return best;
   }
   // small single layers stay with the per-tap kernel: a band workgroup's fixed cost (9 slab tiles) needs several bands of
   // MFMA work behind it (measured: equal at 2.7 GFLOP, 1.3x faster at 10.9 GFLOP, 2.3x slower at 0.68 GFLOP)
-  if (2.0 * B * H * W * Cin * Cout * 9 * njobs < 2.5e9 && !getenv("SST_WGRAD_BAND")) return best;
+  if (2.0 * B * H * W * Cin * Cout * 9 * njobs < 2.5e9 && !sst_env("SST_WGRAD_BAND")) return best;
   const int nblk = (Cout >> 6) * (Cin >> 6);
   long slots = 512;                        // 2 resident workgroups per CU
   int rmax = 2;
-  if (const char* e = getenv("SST_WGRAD_BAND_SLOTS")) slots = atoi(e);      // dev overrides
-  if (const char* e = getenv("SST_WGRAD_BAND_R")) rmax = atoi(e);
+  if (const char* e = sst_env("SST_WGRAD_BAND_SLOTS")) slots = atoi(e);      // dev overrides
+  if (const char* e = sst_env("SST_WGRAD_BAND_R")) rmax = atoi(e);
   double best_cost = 1e30;
   for (int R = rmax; R >= 1; --R) {
     if (H % R) continue;
@@ -725,6 +725,7 @@ struct WgS2Args {
   int tiles_x, tiles_img, ntiles, tpc;          // tiles per row of tiles / per image / in total / per chunk
   int dbg;                                      // ablation bits (SST_WGRAD_S2_DBG, dev): 1 no staging stores, 2 no global loads, 4 no MFMA loop, 8 no exchange
   float* dw; int accumulate;                    // one chunk only (no K split over workgroups): dW[co][ci][tap] written (or added to) directly, no slab
+  int gB;                                       // images per coefficient group (in_scale / in_shift are [B / gB][Cin]: passes batched as one tensor); 0 = one group
 };
 
 // S2_NW waves per workgroup: 8 = two per SIMD, one stages while the other multiplies (256 registers each); 4 = one per SIMD with
@@ -768,6 +769,7 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_tile_kernel(WgS2Args
   f32x4 xr[XQ], dr[DQ];
   unsigned okm = 0;
   bool edge = false;                                     // of the tile whose loads are in xr
+  int goff = 0;                                          // ... and the float offset of its coefficient group in in_scale / in_shift
   const bool lmax = a.in_act == ACT_SLOPE && slope >= 0.f && slope <= 1.f;       // LeakyReLU as max(v, slope * v)
   auto issue = [&](int t, auto edge_) {
     constexpr bool EDGE = decltype(edge_)::value;
@@ -804,6 +806,7 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_tile_kernel(WgS2Args
     return e;
   };
   auto issue_any = [&](int t) {
+    goff = a.gB ? (t / a.tiles_img / a.gB) * a.Cin : 0;
     edge = is_edge(t);
     if (edge) issue(t, std::true_type{}); else issue(t, std::false_type{});
   };
@@ -813,8 +816,8 @@ __global__ __launch_bounds__(S2_NW * 64, 1) void conv_wgrad_tile_kernel(WgS2Args
     constexpr bool EDGE = decltype(edge_)::value;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};      // re-read per tile (cache hits): 8 registers not held across the K loop
     if (a.in_scale) {
-      sc = *reinterpret_cast<const f32x4*>(a.in_scale + ci0 + q4);
-      sh = *reinterpret_cast<const f32x4*>(a.in_shift + ci0 + q4);
+      sc = *reinterpret_cast<const f32x4*>(a.in_scale + goff + ci0 + q4);
+      sh = *reinterpret_cast<const f32x4*>(a.in_shift + goff + ci0 + q4);
     }
 #pragma unroll
     for (int u = 0; u < XQ; ++u) {
@@ -919,7 +922,7 @@ inline WgS2Plan wgrad_s2_plan(int B, int H, int W, int Cin, int Cout, int ksize,
   if (ksize != 3 || (stride != 1 && stride != 2) || (Cin & 31) || (Cout & 31) || B <= 0) return pl;
   if (stride == 2 && ((H | W) & 1)) return pl;
   bool force = false;                                   // SST_WGRAD_S2 / SST_WGRAD_S1T: 0 = off, 1 = also below the work threshold (tests)
-  if (const char* e = getenv(stride == 2 ? "SST_WGRAD_S2" : "SST_WGRAD_S1T")) {
+  if (const char* e = sst_env(stride == 2 ? "SST_WGRAD_S2" : "SST_WGRAD_S1T")) {
     if (atoi(e) == 0) return pl;
     force = true;
   }
@@ -1023,10 +1026,32 @@ SST_API const char* sst_conv_wgrad_kernel_name(int B, int H, int W, int Cin, int
   return ((Cin & 3) == 0 && (Cout & 3) == 0) ? "conv_wgrad_kernel<true>" : "conv_wgrad_kernel<false>";
 }
 
+// Does sst_conv_wgrad_grp take this shape with coefficient groups of grp_images images (the all-taps tile kernel does; a layer whose
+// input has no BatchNorm affine needs no groups at all)?
+SST_API int sst_conv_wgrad_groups_ok(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int grp_images) {
+  return grp_images > 0 && B % grp_images == 0 && wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride).th != 0;
+}
+
+SST_API int sst_conv_wgrad_grp(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
+                               const float* in_shift, const float* in_slope, float in_slope_const, int in_act, int B, int H,
+                               int W, int Cin, int Cout, int stride, int ksize, int accumulate, int grp_images, void* stream);
 SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
                            const float* in_shift, const float* in_slope, float in_slope_const, int in_act, int B, int H,
                            int W, int Cin, int Cout, int stride, int ksize, int accumulate, void* stream) {
+  return sst_conv_wgrad_grp(x, dy, slab, dw, in_scale, in_shift, in_slope, in_slope_const, in_act, B, H, W, Cin, Cout, stride, ksize,
+                            accumulate, 0, stream);
+}
+
+// grp_images > 0: in_scale / in_shift are [B / grp_images][Cin] - images b*grp_images .. use row b (several passes of the network
+// batched as one tensor, each with the BatchNorm coefficients of its own batch statistics; dW sums over all of them).
+SST_API int sst_conv_wgrad_grp(const float* x, const float* dy, float* slab, float* dw, const float* in_scale,
+                               const float* in_shift, const float* in_slope, float in_slope_const, int in_act, int B, int H,
+                               int W, int Cin, int Cout, int stride, int ksize, int accumulate, int grp_images, void* stream) {
   SST_REQUIRE(x && dy && slab && dw, "sst_conv_wgrad: null pointer");
+  const bool grouped = grp_images > 0 && grp_images < B && in_scale;
+  SST_REQUIRE(!grouped || sst_conv_wgrad_groups_ok(B, H, W, Cin, Cout, ksize, stride, grp_images),
+              "sst_conv_wgrad: coefficient groups are only taken by the all-taps tile kernel (B=%d H=%d W=%d Cin=%d Cout=%d stride=%d)", B, H, W,
+              Cin, Cout, stride);
   SST_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) && (ksize & 1) && ksize <= 9,
               "sst_conv_wgrad: bad shape");
   WgradArgs a;
@@ -1042,7 +1067,7 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
   int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
   a.chunk_px = (int)(((M + nchunk - 1) / nchunk + SUB - 1) / SUB * SUB);
   {
-    const char* e = getenv("SST_WGRAD_DBG");
+    const char* e = sst_env("SST_WGRAD_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
   const int KK = ksize * ksize;
@@ -1058,10 +1083,11 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
     s2.x = x; s2.dy = dy; s2.slab = slab; s2.in_scale = in_scale; s2.in_shift = in_shift; s2.in_slope = in_slope;
     s2.in_slope_const = in_slope_const; s2.in_act = in_act;
     s2.B = B; s2.H = H; s2.W = W; s2.Cin = Cin; s2.Cout = Cout; s2.Ho = a.Ho; s2.Wo = a.Wo;
-    s2.dbg = getenv("SST_WGRAD_S2_DBG") ? atoi(getenv("SST_WGRAD_S2_DBG")) : 0;
-    const bool direct = p2.nchunk == 1 && !getenv("SST_WGRAD_TILE_NO_DIRECT");
+    s2.dbg = sst_env("SST_WGRAD_S2_DBG") ? atoi(sst_env("SST_WGRAD_S2_DBG")) : 0;
+    const bool direct = p2.nchunk == 1 && !sst_env("SST_WGRAD_TILE_NO_DIRECT");
     s2.dw = direct ? dw : nullptr;
     s2.accumulate = accumulate & 1;
+    s2.gB = grouped ? grp_images : 0;
     s2.tiles_x = a.Wo / p2.tw; s2.tiles_img = (a.Ho / p2.th) * s2.tiles_x; s2.ntiles = p2.ntiles; s2.tpc = p2.tpc;
     int rc;
     if (stride == 2) rc = p2.tw == 8 ? launch_wgrad_s2_t<2, 2, 8, 8>(s2, p2, sst_stream(stream)) : launch_wgrad_s2_t<2, 2, 6, 8>(s2, p2, sst_stream(stream));
@@ -1079,7 +1105,7 @@ SST_API int sst_conv_wgrad(const float* x, const float* dy, float* slab, float* 
     c3m_reduce_kernel<<<27, 1024, 0, sst_stream(stream)>>>(slab, dw, nchunk, accumulate);
     SST_LAUNCH_CHECK("c3m_reduce_kernel");
     return SST_OK;
-  } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && !getenv("SST_WGRAD_NO_K3C3")) {
+  } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && !sst_env("SST_WGRAD_NO_K3C3")) {
     nchunk = B * ((H + C3_ROWS - 1) / C3_ROWS);
     const size_t lds = (size_t)(C3_ROWS + 2) * ((W + 2) * 3 + 3) * sizeof(float);
     SST_REQUIRE(lds <= 48 * 1024, "sst_conv_wgrad: image too wide for the 3-channel-input kernel (W=%d)", W);
@@ -1118,7 +1144,7 @@ SST_API int sst_conv_wgrad_grouped(const void* jobs, int njobs, int B, int H, in
   int nchunk = sst_conv_wgrad_chunks(B, a.Ho, a.Wo, Cin, Cout, ksize);
   {
     int target = 2048;
-    if (const char* e = getenv("SST_WGRAD_GROUP_WGS")) target = atoi(e);
+    if (const char* e = sst_env("SST_WGRAD_GROUP_WGS")) target = atoi(e);
     const int nblk = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     int want = (target + ksize * ksize * nblk * njobs - 1) / (ksize * ksize * nblk * njobs);
     if (want < 1) want = 1;

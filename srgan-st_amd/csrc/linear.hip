@@ -225,29 +225,51 @@ __global__ __launch_bounds__(NT) void head_fwd_kernel(const float* __restrict__ 
 }
 
 // backward of the head: dh[m][k] = lrelu'(h) * sum_n dy[m][n] w[n][k];  dw[n][k] (+)= sum_m dy[m][n] lrelu(h[m][k]);
-// db[n] (+)= sum_m dy[m][n].   grid over k.
+// db[n] (+)= sum_m dy[m][n].   grid (k blocks, row blocks): a thread takes one k column and HB_ROWS batch rows for dh; the workgroups
+// of the first row block also form dw over all rows (one load of h per row either way - the kernel is a few dependent loads deep
+// instead of M x N of them; the one-thread-per-column form took 50 us at 32 rows).
+constexpr int HB_ROWS = 8;
 __global__ __launch_bounds__(NT) void head_bwd_kernel(const float* __restrict__ h, const float* __restrict__ w,
                                                       const float* __restrict__ dy, float* __restrict__ dh,
                                                       float* __restrict__ dw, float* __restrict__ db, int M, int N, int K,
                                                       float slope, int accumulate) {
   const int k = blockIdx.x * NT + threadIdx.x;
+  const int m0 = blockIdx.y * HB_ROWS, m1 = min(M, m0 + HB_ROWS);
   if (k < K) {
+    float hv[HB_ROWS];
+#pragma unroll
+    for (int i = 0; i < HB_ROWS; ++i) hv[i] = m0 + i < m1 ? h[(size_t)(m0 + i) * K + k] : 0.f;
+    float t[HB_ROWS];
+#pragma unroll
+    for (int i = 0; i < HB_ROWS; ++i) t[i] = 0.f;
     for (int n = 0; n < N; ++n) {
-      float t = 0.f;
-      for (int m = 0; m < M; ++m) {
-        float v = h[(size_t)m * K + k];
-        v = v > 0.f ? v : v * slope;
-        t = fmaf(dy[(size_t)m * N + n], v, t);
-      }
-      if (dw) dw[(size_t)n * K + k] = accumulate ? dw[(size_t)n * K + k] + t : t;
+      const float wv = w[(size_t)n * K + k];
+#pragma unroll
+      for (int i = 0; i < HB_ROWS; ++i)
+        if (m0 + i < m1) t[i] = fmaf(dy[(size_t)(m0 + i) * N + n], wv, t[i]);
     }
-    for (int m = 0; m < M; ++m) {
-      float t = 0.f;
-      for (int n = 0; n < N; ++n) t = fmaf(dy[(size_t)m * N + n], w[(size_t)n * K + k], t);
-      dh[(size_t)m * K + k] = h[(size_t)m * K + k] > 0.f ? t : t * slope;
+#pragma unroll
+    for (int i = 0; i < HB_ROWS; ++i)
+      if (m0 + i < m1) dh[(size_t)(m0 + i) * K + k] = hv[i] > 0.f ? t[i] : t[i] * slope;
+    if (dw && blockIdx.y == 0) {
+      for (int n = 0; n < N; ++n) {
+        float a = 0.f;
+        for (int mb = 0; mb < M; mb += HB_ROWS) {
+          float v[HB_ROWS];
+#pragma unroll
+          for (int i = 0; i < HB_ROWS; ++i) v[i] = mb + i < M ? h[(size_t)(mb + i) * K + k] : 0.f;      // loads of a batch in flight together
+#pragma unroll
+          for (int i = 0; i < HB_ROWS; ++i) {
+            if (mb + i >= M) break;
+            const float x = v[i] > 0.f ? v[i] : v[i] * slope;
+            a = fmaf(dy[(size_t)(mb + i) * N + n], x, a);
+          }
+        }
+        dw[(size_t)n * K + k] = accumulate ? dw[(size_t)n * K + k] + a : a;
+      }
     }
   }
-  if (db && blockIdx.x == 0 && threadIdx.x < N) {
+  if (db && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < N) {
     float t = 0.f;
     for (int m = 0; m < M; ++m) t += dy[(size_t)m * N + threadIdx.x];
     db[threadIdx.x] = accumulate ? db[threadIdx.x] + t : t;
@@ -257,7 +279,8 @@ __global__ __launch_bounds__(NT) void head_bwd_kernel(const float* __restrict__ 
 // flat[b][c*HW + hw] = act(y[b][hw][c] * scale[c] + shift[c])        (NHWC -> NCHW flatten, model.py:69)
 __global__ __launch_bounds__(NT) void flatten_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float slope, int act,
-                                                         float* __restrict__ flat, int B, int HW, int C) {
+                                                         float* __restrict__ flat, int B, int HW, int C, int gB) {
+  // gB: images per coefficient group (scale / shift are [B / gB][C]: passes batched as one tall tensor)
   const int64_t total = (int64_t)B * HW * C;
   for (int64_t i = blockIdx.x * (int64_t)NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
     const int c = (int)(i % C);
@@ -265,7 +288,10 @@ __global__ __launch_bounds__(NT) void flatten_act_kernel(const float* __restrict
     const int hw = (int)(p % HW);
     const int64_t b = p / HW;
     float v = y[i];
-    if (scale) v = fmaf(v, scale[c], shift[c]);
+    if (scale) {
+      const int gc = (int)(b / gB) * C + c;
+      v = fmaf(v, scale[gc], shift[gc]);
+    }
     if (act) v = v > 0.f ? v : v * slope;
     flat[(b * C + c) * HW + hw] = v;
   }
@@ -327,17 +353,24 @@ SST_API int sst_head_fwd(const float* h, const float* w, const float* b, float* 
 SST_API int sst_head_bwd(const float* h, const float* w, const float* dy, float* dh, float* dw, float* db, int M, int N,
                          int K, float slope, int accumulate, void* stream) {
   SST_REQUIRE(h && w && dy && dh && M > 0 && N > 0 && N <= 64 && K > 0, "sst_head_bwd: bad argument");
-  head_bwd_kernel<<<(K + NT - 1) / NT, NT, 0, sst_stream(stream)>>>(h, w, dy, dh, dw, db, M, N, K, slope, accumulate);
+  head_bwd_kernel<<<dim3((K + NT - 1) / NT, (M + HB_ROWS - 1) / HB_ROWS), NT, 0, sst_stream(stream)>>>(h, w, dy, dh, dw, db, M, N, K, slope,
+                                                                                                    accumulate);
   SST_LAUNCH_CHECK("head_bwd_kernel");
   return SST_OK;
 }
 
-SST_API int sst_flatten_act(const float* y, const float* scale, const float* shift, float slope, int act, float* flat,
-                            int B, int HW, int C, void* stream) {
+// grp_images > 0: scale / shift are [B / grp_images][C] (passes batched as one tensor, each with its own BatchNorm coefficients)
+SST_API int sst_flatten_act_grp(const float* y, const float* scale, const float* shift, float slope, int act, float* flat,
+                                int B, int HW, int C, int grp_images, void* stream) {
   SST_REQUIRE(y && flat && B > 0 && HW > 0 && C > 0 && ((scale == nullptr) == (shift == nullptr)), "sst_flatten_act: bad argument");
+  SST_REQUIRE(grp_images >= 0 && (grp_images == 0 || B % grp_images == 0), "sst_flatten_act: bad group size %d for B=%d", grp_images, B);
   const int64_t total = (int64_t)B * HW * C;
   const int blocks = (int)((total + NT - 1) / NT < 2048 ? (total + NT - 1) / NT : 2048);
-  flatten_act_kernel<<<blocks, NT, 0, sst_stream(stream)>>>(y, scale, shift, slope, act, flat, B, HW, C);
+  flatten_act_kernel<<<blocks, NT, 0, sst_stream(stream)>>>(y, scale, shift, slope, act, flat, B, HW, C, grp_images > 0 ? grp_images : B);
   SST_LAUNCH_CHECK("flatten_act_kernel");
   return SST_OK;
+}
+SST_API int sst_flatten_act(const float* y, const float* scale, const float* shift, float slope, int act, float* flat,
+                            int B, int HW, int C, void* stream) {
+  return sst_flatten_act_grp(y, scale, shift, slope, act, flat, B, HW, C, 0, stream);
 }

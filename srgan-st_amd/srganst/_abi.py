@@ -20,6 +20,7 @@ SIGNATURES = {
     "sst_version": (c_int, []),
     "sst_arch": (c_char_p, []),
     "sst_clear_error": (c_int, []),
+    "sst_reload_env": (c_int, []),
     "sst_st_loss_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64)]),
     "sst_st_loss_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_int, P]),
     "sst_st_loss_bwd": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_float, c_float, P]),
@@ -46,6 +47,9 @@ SIGNATURES = {
     "sst_conv_pipe_ws_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_pipe_fwd": (c_int, [P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, c_float, c_int, P, P,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_pipe_groups_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sst_conv_pipe_fwd_grp": (c_int, [P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, c_float, c_int, P, P,
+                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_s2_dgrad_pipe_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_s2_dgrad_pipe_ws_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_s2_dgrad_pipe": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -65,13 +69,20 @@ SIGNATURES = {
     "sst_conv_wgrad_chunks2": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_wgrad": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, P]),
+    "sst_conv_wgrad_groups_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sst_conv_wgrad_grp": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_int, c_int, P]),
     "sst_conv_wgrad_grouped": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_bn_finalize": (c_int, [P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_float, c_float, P]),
+    "sst_bn_finalize_grp": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_float, c_float, P]),
     "sst_bn_eval_affine": (c_int, [P, P, P, P, P, P, c_int, c_float, P]),
     "sst_bn_residual": (c_int, [P, P, P, P, P, P, c_int64, c_int, P]),
     "sst_bwd_reduce_blocks": (c_int, [c_int64, c_int]),
     "sst_bwd_reduce": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, P]),
     "sst_bwd_finalize": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P]),
+    "sst_bwd_reduce_grp": (c_int, [P, P, P, P, P, P, c_float, c_int, P, c_int64, c_int, c_int, P]),
+    "sst_bwd_finalize_grp": (c_int, [P, c_int, c_int, c_float, c_int, P, P, P, P, P, P, P, P, c_int, P]),
+    "sst_bwd_apply_grp": (c_int, [P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int64, c_int, c_int, P]),
     "sst_bwd_finalize_wide": (c_int, [P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, c_int, P, P, P]),
     "sst_act_bwd_partial_blocks": (c_int, [c_int64]),
     "sst_act_bwd_partial": (c_int, [P, P, P, P, c_float, P, P, c_int64, c_int, c_int, c_int, P]),
@@ -118,6 +129,7 @@ SIGNATURES = {
     "sst_head_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P]),
     "sst_head_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P]),
     "sst_flatten_act": (c_int, [P, P, P, c_float, c_int, P, c_int, c_int, c_int, P]),
+    "sst_flatten_act_grp": (c_int, [P, P, P, c_float, c_int, P, c_int, c_int, c_int, c_int, P]),
 }
 
 _lib = None
@@ -141,6 +153,12 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def reload_env() -> None:
+    """The library reads each SST_* dev switch from the environment once; call this after changing one."""
+    if _lib is not None:
+        _lib.sst_reload_env()
 
 
 def check(rc: int, what: str) -> None:

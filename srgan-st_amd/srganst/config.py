@@ -119,8 +119,21 @@ class Config:
         # (= how many layers, counted from the first: the ones the backward chain reaches last; 0 = none, 8 = all)
         self.KERNEL.DEFER_D_WGRAD = int(os.environ.get("SST_DEFER_D_WGRAD", "8"))
         # merged iteration: D's weight packing on the side stream beside the generator's forward
+        # ... with the two passes batched (BATCH_D_STEP) the side branch is the shorter one: nothing is moved (measured: 5.03 ms with
+        # 0 layers deferred, 5.05 / 5.08 / 5.09 / 5.11 with 1 / 2 / 3 / 4, 5.17 with all 8)
+        self.KERNEL.DEFER_D_WGRAD_BATCHED = int(os.environ.get("SST_DEFER_D_WGRAD_B", "0"))
+        # merged iteration: the discriminator's Adam in two launches - the classifier (18.9 of 23.6 M parameters) on the side stream as
+        # soon as its gradient is complete and the generator's backward has read the weights, the feature stack after the join
+        # OFF: measured slower (5.015 vs 4.960 ms, same box): the 75.5 MB classifier's update streams 528 MB through the Infinity Cache
+        # while both branches are running and evicts what their conv kernels were re-reading; at the join nothing else runs
+        self.KERNEL.SPLIT_D_ADAM = os.environ.get("SST_SPLIT_D_ADAM", "0") != "0"
         self.KERNEL.EARLY_D_PACK = os.environ.get("SST_EARLY_D_PACK", "1") != "0"
         self.KERNEL.REUSE_D_SR = os.environ.get("SST_REUSE_D_SR", "1") != "0"
+        # the discriminator step's two passes, D(gt) and D(sr.detach()) (train.py:155-158), as ONE batch of 2B images with per-pass
+        # train-mode BatchNorm statistics (disc_graph.forward on a list of inputs): one launch per layer instead of two, the classifier
+        # weight streamed once per direction.  Same values per pass up to fp32 summation order (the weight gradients sum over 2B images in
+        # one kernel instead of fl(dW_sr + dW_gt)); applies when the step runs both passes (i.e. not on top of REUSE_D_SR's kept pass)
+        self.KERNEL.BATCH_D_STEP = os.environ.get("SST_BATCH_D_STEP", "1") != "0"
         self.KERNEL.LR_ON_DEVICE = False    # True: the LR batch is synthesised from the GT batch on the GPU (sst_bicubic, same
                                             # values as dataset.py:28 on the 1/255 grid) instead of taking the loader's copy
 

@@ -50,8 +50,31 @@ def _packs(module, p, with_dgrad):
     return wp, wd, ws2
 
 
+def groups_supported(module, p, gB, groups, H, W):
+    """Can `groups` passes of gB images each (H x W) run as ONE batch with per-pass BatchNorm statistics?  Every BatchNorm layer's
+    producer and consumer must be on the kernels that take coefficient groups (the pipelined conv, the all-taps weight gradient)."""
+    B = gB * groups
+    h, w = H, W
+    for li, (ci, bi, stride) in enumerate(PLAN):
+        wt = p[f"features.{ci}.weight"]
+        cout, cin = wt.shape[0], wt.shape[1]
+        if li > 0:
+            if not ops.conv_pipe_groups_ok(B, h, w, cin, cout, 3, stride, gB):
+                return False
+            if stride == 1 and not ops.conv_pipe_groups_ok(B, h, w, cout, cin, 3, 1, gB):      # its data-gradient (epilogue partials)
+                return False
+            if not ops._abi.lib().sst_conv_wgrad_groups_ok(B, h, w, cin, cout, 3, stride, gB):
+                return False
+        h, w = ops.conv_out_hw(h, w, 3, stride)
+    return B <= 64            # classifier kernels: at most 64 batch rows
+
+
 def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook=None, update_running=True):
-    """bump_counters=False: the caller has already added this pass to num_batches_tracked (two passes on two streams must
+    """x: one NCHW batch, or a LIST of `groups` equally-shaped NCHW batches = that many passes of the discriminator run as ONE
+    batch (each pass keeps its own train-mode BatchNorm statistics: per-pass scale / shift rows, running statistics updated pass by
+    pass in list order, batch counters + groups) - the discriminator step's D(gt) and D(sr.detach()) (train.py:155-158) as one tall
+    image; returns logits [groups * B, 1] and saved tensors with sv["groups"], sv["gB"].
+    bump_counters=False: the caller has already added this pass to num_batches_tracked (two passes on two streams must
     not race on the counters).  bn_hook(li, when) is called right before ("pre") / after ("post") each train-mode
     bn_finalize - the only kernels of a forward that write shared state (running statistics): a caller that runs two passes
     concurrently orders them there.  update_running=False: the pass leaves the running statistics and the batch counter alone;
@@ -59,18 +82,32 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
     in the reference's sequence)."""
     if not update_running:
         bump_counters = False
-    sv = {"layers": []}
+    groups, gB = 1, 0
+    if isinstance(x, (list, tuple)):
+        groups, gB = len(x), x[0].shape[0]
+        if groups == 1:
+            x, gB = x[0], 0
+        elif not training:
+            raise NotImplementedError("batched passes are a train-mode schedule (eval mode has no per-pass statistics to keep apart)")
+    sv = {"layers": [], "groups": groups, "gB": gB}
     wp, sv["wd"], sv["ws2"] = _packs(module, p, need_grad)
     if training and bump_counters and not module.__dict__.get("_counters_external"):
-        ops.flatten_bn_counters(module).add_(1)
-    x3 = ops.transpose(x.contiguous(), to_nchw=False)
+        ops.flatten_bn_counters(module).add_(groups)
+    if groups > 1:
+        _, c3, hh, ww = x[0].shape
+        x3 = torch.empty(groups * gB, hh, ww, c3, device=x[0].device, dtype=torch.float32)
+        for gi, xi in enumerate(x):
+            assert xi.shape == x[0].shape
+            ops.transpose(xi.contiguous(), to_nchw=False, out=x3[gi * gB:(gi + 1) * gB])
+    else:
+        x3 = ops.transpose(x.contiguous(), to_nchw=False)
     h, scale, shift, act = x3, None, None, 0
     for ci, bi, stride in PLAN:
         w = p[f"features.{ci}.weight"]
         cout = w.shape[0]
         bias = p.get(f"features.{ci}.bias")
         y, _, st, cnt = ops.conv_fwd(h, wp[f"features.{ci}.weight"], cout, 3, stride, bias=bias, in_scale=scale, in_shift=shift,
-                                     in_slope_const=LRELU, in_act=act, want_stats=(bi is not None and training))
+                                     in_slope_const=LRELU, in_act=act, want_stats=(bi is not None and training), grp=gB)
         rec = {"x": h, "x_scale": scale, "x_shift": shift, "x_act": act, "y": y, "ci": ci, "bi": bi, "stride": stride}
         if bi is not None:
             bn = module.features[bi]
@@ -79,7 +116,7 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
                 if bn_hook is not None:
                     bn_hook(len(sv["layers"]), "pre")
                 mean, rstd, scale, shift = ops.bn_finalize(st, cnt, g, b, bn.running_mean if update_running else None,
-                                                           bn.running_var if update_running else None)
+                                                           bn.running_var if update_running else None, groups=groups)
                 if bn_hook is not None:
                     bn_hook(len(sv["layers"]), "post")
                 rec["mean"], rec["rstd"] = mean, rstd
@@ -91,7 +128,7 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
         rec["scale"], rec["shift"] = scale, shift
         sv["layers"].append(rec)
         h, act = y, ACT_SLOPE
-    flat = ops.flatten_act(h, scale, shift, LRELU, 1)                       # [B, C*H*W]  (C,H,W) order
+    flat = ops.flatten_act(h, scale, shift, LRELU, 1, grp=gB)               # [B, C*H*W]  (C,H,W) order
     h1 = ops.linear_fwd(flat, p["classifier.0.weight"], p["classifier.0.bias"])   # pre-activation
     out = ops.head_fwd(h1, p["classifier.2.weight"], p["classifier.2.bias"], LRELU)
     sv["flat"], sv["h1"] = flat, h1
@@ -105,14 +142,15 @@ def replay_running_stats(module, p, sv):
     per-tile partials, i.e. the very launch the forward would issue) and of num_batches_tracked.  engine.TrainEngine uses it for
     the discriminator step's D(sr.detach()) (train.py:158), which repeats the generator step's D(sr) (train.py:136) before any
     weight has changed."""
+    groups = sv.get("groups", 1)
     if not module.__dict__.get("_counters_external"):
-        ops.flatten_bn_counters(module).add_(1)
+        ops.flatten_bn_counters(module).add_(groups)
     for rec in sv["layers"]:
         if rec["bi"] is None:
             continue
         bn = module.features[rec["bi"]]
         ops.bn_finalize(rec["st"], rec["cnt"], p[f"features.{rec['bi']}.weight"], p[f"features.{rec['bi']}.bias"],
-                        bn.running_mean, bn.running_var)
+                        bn.running_mean, bn.running_var, groups=groups)
 
 
 def _grad_views(module, p, need_param_grads):
@@ -176,12 +214,13 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
 
     wg = need_param_grads
     dx = None
+    groups, gB = sv.get("groups", 1), sv.get("gB", 0)      # passes batched as one tall image: per-pass coefficient rows
     wd, ws2 = sv["wd"], sv["ws2"]               # packed (or re-used) by the forward
     part = None                      # BN/activation backward partials of g, when the producing dgrad conv emitted them
     for li in reversed(range(len(sv["layers"]))):
         r = sv["layers"][li]
         y = r["y"]
-        n = y.numel() // y.shape[-1]
+        n = y.numel() // y.shape[-1] // groups      # elements per channel of ONE pass (each has its own batch statistics)
         ci, bi = r["ci"], r["bi"]
         w = p[f"features.{ci}.weight"]
         if bi is not None:
@@ -189,20 +228,20 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
             dg = G(f"features.{bi}.weight") if wg else torch.empty_like(gam)
             db = G(f"features.{bi}.bias") if wg else torch.empty_like(gam)
             kw = dict(scale=r["scale"], shift=r["shift"], slope_const=LRELU, act=1, mean=r["mean"], rstd=r["rstd"], gamma=gam,
-                      dgamma=dg, dbeta=db, accumulate=acc and wg)
+                      dgamma=dg, dbeta=db, accumulate=acc and wg, groups=groups)
             dy = ops.bwd_finalize_apply(part, g, y, n, **kw) if part is not None else ops.bwd_reduce_apply(g, y, n, **kw)
         elif wg:
-            kw = dict(slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"), accumulate=acc)
+            kw = dict(slope_const=LRELU, act=1, dbeta=G(f"features.{ci}.bias"), accumulate=acc, groups=groups)
             dy = ops.bwd_finalize_apply(part, g, y, n, **kw) if part is not None else ops.bwd_reduce_apply(g, y, n, **kw)
         else:
-            dy = ops.bwd_apply(g, y, slope_const=LRELU, act=1)
+            dy = ops.bwd_apply(g, y, slope_const=LRELU, act=1, groups=groups)
         part = None
         if wg:
             dwc = G(f"features.{ci}.weight")
 
             def launch(r=r, dy=dy, dwc=dwc):
                 ops.conv_wgrad(r["x"], dy, dwc, 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
-                               in_slope_const=LRELU, in_act=r["x_act"], accumulate=acc)
+                               in_slope_const=LRELU, in_act=r["x_act"], accumulate=acc, grp=gB)
             if defer_wgrad is not None and (defer_below is None or li < defer_below):
                 ev = torch.cuda.Event()
                 ev.record()
@@ -218,7 +257,7 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
                 prev = sv["layers"][li - 1]
                 g, part = ops.conv_dgrad_bwdstats(dy, wd[f"features.{ci}.weight"], w.shape[1], 3, prev["y"],
                                                   epi_scale=prev["scale"], epi_shift=prev["shift"], epi_slope_const=LRELU,
-                                                  epi_act=1)
+                                                  epi_act=1, grp=gB)
             else:
                 g = ops.conv_fwd(dy, wd[f"features.{ci}.weight"], w.shape[1], 3, 1)[0]
         else:
@@ -227,7 +266,7 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
             # or parameter gradients are wanted (its bias)
             prev = sv["layers"][li - 1] if li > 0 else None
             epi = None
-            if prev is not None and (prev["bi"] is not None or wg):
+            if groups == 1 and prev is not None and (prev["bi"] is not None or wg):      # (batched passes: the separate reduce pass takes the groups)
                 epi = dict(y=prev["y"], scale=prev["scale"], shift=prev["shift"], slope_const=LRELU, act=1)
             out = ops.conv_s2_dgrad(dy, ws2[f"features.{ci}.weight"], xin.shape[1], xin.shape[2], w.shape[1], epi=epi)
             g, part = out if epi is not None else (out, None)
@@ -241,6 +280,9 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
 
 def backward(module, p, sv, dout, need_param_grads, need_dx):
     st = backward_classifier(module, p, sv, dout, need_param_grads)
+    hook = module.__dict__.get("_after_cls_bwd")
+    if hook is not None:             # engine.TrainEngine: the classifier's weights have been read for the last time on this stream
+        hook()
     return backward_features(module, p, sv, st, need_param_grads, need_dx)
 
 

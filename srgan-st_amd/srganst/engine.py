@@ -265,6 +265,7 @@ class TrainEngine:
         # ([fwd+bwd] -> all-reduce -> wait -> [Adam] per network); both give bit-identical parameters (tests/test_dp_gpu.py).
         self.overlap = self.dp and (config.DIST.OVERLAP_COMM if overlap_comm is None else overlap_comm)
         self._d_a = self._d_b = self._g_f = self._g_b = None
+        self.d_batched = False           # set once the discriminator step has run its two passes as one batch (KERNEL.BATCH_D_STEP)
         self.d_sr_reused = False         # set once the discriminator step has run on the generator step's D(sr) pass (KERNEL.REUSE_D_SR)
         self._side = self._side_d = None
         self._it = None
@@ -403,6 +404,29 @@ class TrainEngine:
             p.requires_grad = True
         self.d_opt.zero_grad(set_to_none=True)
         names = [n for n, _ in D.named_parameters()]
+        kept = D.__dict__.get("_last_pass") if self.config.KERNEL.REUSE_D_SR else None
+        if early_gt is None and kept is None and self.config.KERNEL.BATCH_D_STEP:
+            pd = dict(zip(names, [t.detach() for t in D.parameters()]))
+            B = self.gt.shape[0]
+            if self.sr.shape == self.gt.shape and disc_graph.groups_supported(D, pd, B, 2, self.gt.shape[2], self.gt.shape[3]):
+                # Both passes of the step as ONE batch [gt ; sr] with per-pass BatchNorm statistics (running statistics move in the
+                # reference's order: gt, then sr), one backward over 2B images.
+                D.__dict__.pop("_last_pass", None)
+                pred, sv = disc_graph.forward(D, [self.gt, self.sr], pd, True, True)
+                pred_gt, pred_sr = pred[:B], pred[B:]
+                dl = torch.empty_like(pred)
+                loss_real, _ = ops.bce_logits(pred_gt, self.real, want_loss=True, want_grad=True, grad_out=dl[:B])
+                loss_fake, _ = ops.bce_logits(pred_sr, self.fake, want_loss=True, want_grad=True, grad_out=dl[B:])
+                self.d_loss, self.pred_gt, self.pred_sr = loss_real + loss_fake, pred_gt, pred_sr
+                st = disc_graph.backward_classifier(D, pd, sv, dl, True)
+                self._d_state = (pd, None, None, sv, st)
+                self.d_batched = True
+                flat = D.__dict__["_flat_grads"][-1]
+                plist = [pd[n] for n in names]
+                offs, total = ops.flat_layout(plist)
+                cut = offs[names.index("classifier.0.weight")]
+                self._d_flat, self._d_buckets = flat, (flat[cut:total], flat[:cut])
+                return self.d_loss
         if early_gt is not None:
             pd, pred_gt, sv_gt = early_gt
             disc_graph.replay_running_stats(D, pd, sv_gt)
@@ -418,7 +442,7 @@ class TrainEngine:
         if (kept is not None and kept["x_ptr"] == self.sr.data_ptr() and kept["x_shape"] == tuple(self.sr.shape)
                 and all(kept["p"][n].data_ptr() == pd[n].data_ptr() and kept["p"][n]._version == pd[n]._version for n in names)):
             disc_graph.replay_running_stats(D, pd, kept["sv"])
-            pred_sr, sv_sr = kept["out"], kept["sv"]
+            pred_sr, sv_sr = kept["out"].detach(), kept["sv"]
             self.d_sr_reused = True
         else:
             pred_sr, sv_sr = disc_graph.forward(D, self.sr, pd, True, True)
@@ -443,9 +467,13 @@ class TrainEngine:
         (disc_graph.backward_features); they ADD into what the D(sr) pass wrote, which is complete by then on this stream."""
         from . import disc_graph
         pd, sv_sr, st_sr, sv_gt, st_gt = self._d_state
-        grads, _ = disc_graph.backward_features(self.D, pd, sv_sr, st_sr, True, False)
-        disc_graph.backward_features(self.D, pd, sv_gt, st_gt, True, False, defer_wgrad=defer_gt_wgrad,
-                                     defer_below=int(self.config.KERNEL.DEFER_D_WGRAD))
+        if sv_sr is None:               # both passes as one batch (_d_fwd_cls): one backward, its weight gradients are the leaves
+            grads, _ = disc_graph.backward_features(self.D, pd, sv_gt, st_gt, True, False, defer_wgrad=defer_gt_wgrad,
+                                                    defer_below=int(self.config.KERNEL.DEFER_D_WGRAD_BATCHED))
+        else:
+            grads, _ = disc_graph.backward_features(self.D, pd, sv_sr, st_sr, True, False)
+            disc_graph.backward_features(self.D, pd, sv_gt, st_gt, True, False, defer_wgrad=defer_gt_wgrad,
+                                         defer_below=int(self.config.KERNEL.DEFER_D_WGRAD))
         for n, p in self.D.named_parameters():
             p.grad = grads[n]
 
@@ -552,20 +580,43 @@ class TrainEngine:
         self.sr = sr.detach()
         ops.debug_stamp(2)
         self._side_d.wait_stream(main)
-        with torch.cuda.stream(self._side_d):   # both passes on ONE side stream: a third concurrent branch (the two passes on two
+        side = self._side_d
+        with torch.cuda.stream(side):           # both passes on ONE side stream: a third concurrent branch (the two passes on two
             ops.debug_stamp(3)
             self._d_fwd_cls(early_gt)           # streams, as _d_two_stream does on its own) crashed hipStreamEndCapture (ROCm 7.2)
             ops.debug_stamp(4)
-            deferred = [] if cfg.KERNEL.DEFER_D_WGRAD else None
-            self._d_features(deferred)
-            ops.debug_stamp(5)
+        # D's Adam in two parts (KERNEL.SPLIT_D_ADAM): the classifier's gradient is complete here; its weights are read once more,
+        # by the head of the generator's backward (through D), which hands over with an event - then the classifier's update runs on
+        # the side stream beside the rest of both branches and only the feature stack's (4.7 M parameters) is left for the join.
+        names = [n for n, _ in self.D.named_parameters()]
+        cls0 = names.index("classifier.0.weight")
+        split = bool(cfg.KERNEL.SPLIT_D_ADAM) and self._d_flat is not None and hasattr(self.d_opt, "step_params")
+
+        def cls_adam():
+            ev = torch.cuda.Event()
+            ev.record()                          # on the stream the backward runs on
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                self.d_opt.step_params(cls0, len(names), flat_grad=self._d_flat)
+        if split:
+            if adv_d:
+                self.D.__dict__["_after_cls_bwd"] = cls_adam
+            else:
+                cls_adam()
         ops.debug_stamp(6)
-        with torch.autograd.set_multithreading_enabled(False):      # backward on this thread: one thread feeds the open capture
-            total.backward(_one(total))
+        try:
+            with torch.autograd.set_multithreading_enabled(False):      # backward on this thread: one thread feeds the open capture
+                total.backward(_one(total))
+        finally:
+            self.D.__dict__.pop("_after_cls_bwd", None)
         ops.debug_stamp(7)
         self.loss_values = vals
         self.g_opt.step()
         ops.debug_stamp(8)
+        with torch.cuda.stream(side):           # (issued after the generator's backward: the classifier's Adam sits in front of it)
+            deferred = [] if cfg.KERNEL.DEFER_D_WGRAD else None
+            self._d_features(deferred)
+            ops.debug_stamp(5)
         # The side branch is the longer one (D(gt) forward + two backward passes against one generator backward).  The conv weight
         # gradients of its last pass are leaves of that chain: they run HERE, on the generator's stream, which would otherwise idle
         # until the join - each behind the event of its dy.  Same kernels, same arguments, same accumulation order per parameter
@@ -579,7 +630,11 @@ class TrainEngine:
                         t.record_stream(main)   # is destroyed after the capture, left the allocator with a dangling stream (segfaults in later replays)
             launch()
         main.wait_stream(self._side_d)
-        self._d_step()
+        if split:
+            self.d_opt.step_params(0, cls0, flat_grad=self._d_flat)
+            self.D.__dict__["_packs_fresh"] = False      # weights changed
+        else:
+            self._d_step()
         self.D.__dict__["_counters_external"] = False
         ops.debug_stamp(9)
         return vals
@@ -603,6 +658,7 @@ class TrainEngine:
         self._g_fb = self._g_op = self._d_fb = self._d_op = self._d_a = self._d_b = self._it = self._g_f = self._g_b = None
         self._g_total = None
         self._d_state = self._d_flat = self._d_buckets = None
+        self.D.__dict__.pop("_last_pass", None)
         self.gt = self.lr = self.sr = None
 
     def _step_overlapped(self):

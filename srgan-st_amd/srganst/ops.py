@@ -88,11 +88,18 @@ def conv_out_hw(h, w, k, stride):
 
 def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=None, in_slope=None,
              in_slope_const=0.0, in_act=ACT_NONE, residual=None, want_stats=False, out_mode=OUT_NHWC,
-             want_pre=False):
-    """x [B,H,W,Cin] NHWC -> y (layout per out_mode); returns (y, y_pre|None, stats|None, cnt|None)."""
+             want_pre=False, grp=0, out=None):
+    """x [B,H,W,Cin] NHWC -> y (layout per out_mode); returns (y, y_pre|None, stats|None, cnt|None).
+    grp > 0: the batch is B / grp passes of grp images each, in_scale / in_shift are [B / grp, Cin] (pipelined kernel only)."""
     B, H, W, cin = x.shape
+    if grp and grp < B and in_scale is not None and not (out_mode == OUT_NHWC and residual is None and not want_pre
+                                                         and conv_pipe_groups_ok(B, H, W, cin, cout, ksize, stride, grp)):
+        raise _abi.HipPathError(f"conv_fwd: coefficient groups of {grp} images are not supported for this shape")
     ho, wo = conv_out_hw(H, W, ksize, stride)
-    if out_mode == OUT_NHWC:
+    if out is not None:
+        assert out_mode == OUT_NHWC and tuple(out.shape) == (B, ho, wo, cout) and out.is_contiguous()
+        y = out
+    elif out_mode == OUT_NHWC:
         y = _f32(B, ho, wo, cout, like=x)
     elif out_mode == OUT_SHUFFLE:
         y = _f32(B, 2 * ho, 2 * wo, cout // 4, like=x)
@@ -102,7 +109,7 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
         y = _f32(B, ho // 2, wo // 2, cout * 4, like=x)
     if out_mode == OUT_NHWC and residual is None and not want_pre and conv_pipe_tw(B, H, W, cin, cout, ksize, stride):
         y, stats, cnt, _ = _conv_pipe(x, wp, y, cout, ksize, stride, bias, in_scale, in_shift, in_slope, in_slope_const, in_act,
-                                      want_stats)
+                                      want_stats, grp=grp)
         return y, None, stats, cnt
     y_pre = torch.empty_like(y) if want_pre else None
     stats = cnt = None
@@ -130,8 +137,14 @@ def conv_pipe_tw(B, H, W, cin, cout, ksize, stride):
     return _abi.lib().sst_conv_pipe_supported(B, H, W, cin, cout, ksize, stride)
 
 
+def conv_pipe_groups_ok(B, H, W, cin, cout, ksize, stride, grp):
+    """The pipelined conv kernel takes this shape AND passes of `grp` images end on its tile boundaries."""
+    return bool(conv_pipe_tw(B, H, W, cin, cout, ksize, stride)) and \
+        bool(_abi.lib().sst_conv_pipe_groups_ok(B, H, W, cin, cout, ksize, stride, int(grp)))
+
+
 def _conv_pipe(x, wp, y, cout, ksize, stride, bias=None, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,
-               in_act=ACT_NONE, want_stats=False, epi=None):
+               in_act=ACT_NONE, want_stats=False, epi=None, grp=0):
     """sst_conv_pipe_fwd: forward statistics (want_stats) or backward partials (epi = dict(y, scale, shift, slope, slope_const,
     act)); returns (y, stats, cnt, partial)."""
     B, H, W, cin = x.shape
@@ -148,14 +161,14 @@ def _conv_pipe(x, wp, y, cout, ksize, stride, bias=None, in_scale=None, in_shift
     ws = _f32(nws, like=x) if nws else None
     args = (ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const), int(in_act),
             ptr(stats), ptr(cnt), ptr(e.get("y")), ptr(e.get("scale")), ptr(e.get("shift")), ptr(e.get("slope")),
-            float(e.get("slope_const", 0.0)), int(e.get("act", 0)), ptr(partial), ptr(ws), *shp)
+            float(e.get("slope_const", 0.0)), int(e.get("act", 0)), ptr(partial), ptr(ws), *shp, int(grp))
     e0 = _prof_begin()
-    check(L.sst_conv_pipe_fwd(*args, stream_ptr()), "sst_conv_pipe_fwd")
+    check(L.sst_conv_pipe_fwd_grp(*args, stream_ptr()), "sst_conv_pipe_fwd")
     ho, wo = conv_out_hw(H, W, ksize, stride)
     flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
     name = f"conv_pipe_kernel<{stride}, {L.sst_conv_pipe_supported(*shp)}, 0>" if (PROFILE is not None or TRACE is not None) else ""
     _prof_end(e0, name, flops)
-    _trace(name, flops, lambda: L.sst_conv_pipe_fwd(*args, stream_ptr()),
+    _trace(name, flops, lambda: L.sst_conv_pipe_fwd_grp(*args, stream_ptr()),
            x, wp, y, bias, in_scale, in_shift, in_slope, stats, cnt, partial, ws, *[v for v in e.values() if torch.is_tensor(v)])
     return y, stats, cnt, partial
 
@@ -270,8 +283,9 @@ def bn_finalize_acc(acc, n, gamma, beta, run_mean=None, run_var=None):
 
 
 def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,
-               in_act=ACT_NONE, accumulate=False):
-    """dw_out [Cout,Cin,k,k] (reference layout) (+)= wgrad.  x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC."""
+               in_act=ACT_NONE, accumulate=False, grp=0):
+    """dw_out [Cout,Cin,k,k] (reference layout) (+)= wgrad.  x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC.
+    grp > 0: B / grp passes of grp images, in_scale / in_shift [B / grp, Cin] (all-taps tile kernel only)."""
     B, H, W, cin = x.shape
     cout = dy.shape[-1]
     ho, wo = conv_out_hw(H, W, ksize, stride)
@@ -280,26 +294,29 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
     slab = _f32(nch * ksize * ksize * cout * cin, like=x)
     e0 = _prof_begin()
     args = (ptr(x), ptr(dy), ptr(slab), ptr(dw_out), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const),
-            int(in_act), B, H, W, cin, cout, stride, ksize, int(accumulate))
-    check(_abi.lib().sst_conv_wgrad(*args, stream_ptr()), "sst_conv_wgrad")
+            int(in_act), B, H, W, cin, cout, stride, ksize, int(accumulate), int(grp))
+    check(_abi.lib().sst_conv_wgrad_grp(*args, stream_ptr()), "sst_conv_wgrad")
     flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
     name = ""
     if PROFILE is not None or TRACE is not None:
         name = _wgrad_name(B, H, W, cin, cout, ksize, stride, 1)
         name += "+c3m_reduce_kernel" if name == "wgrad_k3c3_mfma_kernel" else "+wgrad_reduce_kernel"
     _prof_end(e0, name, flops)
-    _trace(name, flops, lambda: _abi.lib().sst_conv_wgrad(*args, stream_ptr()),
+    _trace(name, flops, lambda: _abi.lib().sst_conv_wgrad_grp(*args, stream_ptr()),
            x, dy, slab, dw_out, in_scale, in_shift, in_slope)
     return dw_out
 
 
-def bn_finalize(stats, cnt, gamma, beta, run_mean=None, run_var=None, eps=BN_EPS, momentum=BN_MOMENTUM):
-    """-> (mean, rstd, scale, shift); updates run_mean/run_var in place when given (train mode)."""
+def bn_finalize(stats, cnt, gamma, beta, run_mean=None, run_var=None, eps=BN_EPS, momentum=BN_MOMENTUM, groups=1):
+    """-> (mean, rstd, scale, shift); updates run_mean/run_var in place when given (train mode).
+    groups > 1: the tiles are `groups` equal consecutive ranges (passes batched as one tall image): outputs [groups, C], one momentum
+    step of the running statistics per group, in order."""
     C = gamma.numel()
-    mean, rstd, scale, shift = (_f32(C, like=gamma) for _ in range(4))
-    check(_abi.lib().sst_bn_finalize(ptr(stats), ptr(cnt), stats.shape[0], C, ptr(gamma), ptr(beta), ptr(run_mean),
-                                     ptr(run_var), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), eps, momentum,
-                                     stream_ptr()), "sst_bn_finalize")
+    shape = (C,) if groups == 1 else (groups, C)
+    mean, rstd, scale, shift = (_f32(*shape, like=gamma) for _ in range(4))
+    check(_abi.lib().sst_bn_finalize_grp(ptr(stats), ptr(cnt), stats.shape[0], C, int(groups), ptr(gamma), ptr(beta), ptr(run_mean),
+                                         ptr(run_var), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), eps, momentum,
+                                         stream_ptr()), "sst_bn_finalize")
     return mean, rstd, scale, shift
 
 
@@ -319,20 +336,31 @@ def bn_residual(y, scale, shift, res, res_slope=None):
     return out
 
 
-def bwd_reduce(g, y, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0):
+def bwd_reduce(g, y, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, groups=1):
+    """groups > 1: y is `groups` passes stacked along the rows, scale / shift [groups, C]; partial [groups * nblk, 3, C]."""
     C = y.shape[-1]
-    R = y.numel() // C
+    R = y.numel() // C // groups
     nblk = _abi.lib().sst_bwd_reduce_blocks(R, C)
-    partial = _f32(nblk, 3, C, like=y)
-    check(_abi.lib().sst_bwd_reduce(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
-                                    ptr(partial), R, C, stream_ptr()), "sst_bwd_reduce")
+    partial = _f32(groups * nblk, 3, C, like=y)
+    check(_abi.lib().sst_bwd_reduce_grp(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
+                                        ptr(partial), R, C, int(groups), stream_ptr()), "sst_bwd_reduce")
     return partial
 
 
-def bwd_finalize(partial, n, mean=None, rstd=None, gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False):
-    """BN mode (mean given): fills dgamma/dbeta, returns (cA,cB,cC).  Otherwise dbeta (= dbias) / dslope only."""
+def bwd_finalize(partial, n, mean=None, rstd=None, gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, groups=1):
+    """BN mode (mean given): fills dgamma/dbeta, returns (cA,cB,cC).  Otherwise dbeta (= dbias) / dslope only.
+    groups > 1: partial holds `groups` consecutive ranges of blocks, mean / rstd and the returned coefficients are [groups, C], n counts
+    one pass; dgamma / dbeta sum over the passes."""
     nblk, _, C = partial.shape
     cA = cB = cC = None
+    if groups > 1:
+        assert dslope is None and nblk % groups == 0
+        if mean is not None:
+            cA, cB, cC = (_f32(groups, C, like=partial) for _ in range(3))
+        check(_abi.lib().sst_bwd_finalize_grp(ptr(partial), nblk // groups, C, float(n), int(groups), ptr(mean), ptr(rstd), ptr(gamma),
+                                              ptr(dgamma), ptr(dbeta), ptr(cA), ptr(cB), ptr(cC), int(accumulate), stream_ptr()),
+              "sst_bwd_finalize_grp")
+        return cA, cB, cC
     if mean is not None:
         cA, cB, cC = (_f32(C, like=partial) for _ in range(3))
     if dslope is not None and C > 64:        # wide layer: keep the finalize channel-parallel (last-arriver slope sum)
@@ -369,10 +397,17 @@ def act_bwd(g, y, g2=None, slope=None, slope_const=0.0, dbias=None, dslope=None,
 
 
 def bwd_apply(g, y, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, cA=None, cB=None, cC=None,
-              unshuffle=False):
+              unshuffle=False, groups=1):
     """dy = cA*gz + cB*y + cC (BN input grad) or gz (activation grad only).  unshuffle: y is [B,2h,2w,C] and dy
-    is stored as the pre-PixelShuffle tensor [B,h,w,4C]."""
+    is stored as the pre-PixelShuffle tensor [B,h,w,4C].  groups > 1: passes stacked along the rows, coefficients [groups, C]."""
     C = y.shape[-1]
+    if groups > 1:
+        assert not unshuffle
+        dy = torch.empty_like(y)
+        check(_abi.lib().sst_bwd_apply_grp(ptr(g), ptr(g2), ptr(y), ptr(scale), ptr(shift), ptr(slope), float(slope_const), int(act),
+                                           ptr(cA), ptr(cB), ptr(cC), ptr(dy), y.numel() // C // groups, C, int(groups), stream_ptr()),
+              "sst_bwd_apply_grp")
+        return dy
     uh = uw = 0
     if unshuffle:
         B, uh, uw, _ = y.shape
@@ -391,14 +426,17 @@ def add(a, b):
     return out
 
 
-def transpose(x, to_nchw: bool):
+def transpose(x, to_nchw: bool, out=None):
     """NHWC [B,H,W,C] -> NCHW [B,C,H,W] (to_nchw) or the inverse."""
     if to_nchw:
         B, H, W, C = x.shape
-        out = _f32(B, C, H, W, like=x)
+        shape = (B, C, H, W)
     else:
         B, C, H, W = x.shape
-        out = _f32(B, H, W, C, like=x)
+        shape = (B, H, W, C)
+    if out is None:
+        out = _f32(*shape, like=x)
+    assert tuple(out.shape) == shape and out.is_contiguous()
     check(_abi.lib().sst_transpose(ptr(x), ptr(out), B, C, H, W, int(to_nchw), stream_ptr()), "sst_transpose")
     return out
 
@@ -435,9 +473,9 @@ def pixel_loss_bwd(x, gt, mode, scale_dev=None, scale_host=1.0, out=None, accumu
     return out
 
 
-def bce_logits(logits, target, want_loss=True, want_grad=False, scale_dev=None, scale_host=1.0):
+def bce_logits(logits, target, want_loss=True, want_grad=False, scale_dev=None, scale_host=1.0, grad_out=None):
     loss = _f32((), like=logits) if want_loss else None
-    dl = torch.empty_like(logits) if want_grad else None
+    dl = (grad_out if grad_out is not None else torch.empty_like(logits)) if want_grad else None
     check(_abi.lib().sst_bce_logits(ptr(logits), float(target), ptr(loss), ptr(dl), ptr(scale_dev), float(scale_host),
                                     logits.numel(), stream_ptr()), "sst_bce_logits")
     return loss, dl
@@ -562,12 +600,12 @@ def head_bwd(h, w, dy, slope, dw=None, db=None, accumulate=False):
     return dh
 
 
-def flatten_act(y, scale, shift, slope, act=1):
-    """NHWC [B,H,W,C] -> [B, C*H*W] in NCHW-flatten order with act(y*scale+shift) applied."""
+def flatten_act(y, scale, shift, slope, act=1, grp=0):
+    """NHWC [B,H,W,C] -> [B, C*H*W] in NCHW-flatten order with act(y*scale+shift) applied (grp > 0: scale / shift [B / grp, C])."""
     B, H, W, C = y.shape
     flat = _f32(B, C * H * W, like=y)
-    check(_abi.lib().sst_flatten_act(ptr(y), ptr(scale), ptr(shift), float(slope), int(act), ptr(flat), B, H * W, C,
-                                     stream_ptr()), "sst_flatten_act")
+    check(_abi.lib().sst_flatten_act_grp(ptr(y), ptr(scale), ptr(shift), float(slope), int(act), ptr(flat), B, H * W, C, int(grp),
+                                         stream_ptr()), "sst_flatten_act")
     return flat
 
 
@@ -743,13 +781,14 @@ def conv9_to3_fwd(x, w, bias=None, in_slope=None, in_slope_const=0.0, in_act=ACT
 
 
 def bwd_reduce_apply(g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
-                     gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False):
+                     gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False, groups=1):
     """Backward through [BatchNorm ->] activation: row-parallel reduction, channel-parallel finalize (BN-backward
-    coefficients + dgamma / dbeta / dslope), elementwise apply.  Returns dy (pre-PixelShuffle layout when unshuffle)."""
-    part = bwd_reduce(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act)
-    cA, cB, cC = bwd_finalize(part, n, mean, rstd, gamma, dgamma, dbeta, dslope, accumulate)
+    coefficients + dgamma / dbeta / dslope), elementwise apply.  Returns dy (pre-PixelShuffle layout when unshuffle).
+    groups > 1: passes stacked along the rows (n = elements per channel of ONE pass)."""
+    part = bwd_reduce(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act, groups=groups)
+    cA, cB, cC = bwd_finalize(part, n, mean, rstd, gamma, dgamma, dbeta, dslope, accumulate, groups=groups)
     return bwd_apply(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act, cA=cA, cB=cB, cC=cC,
-                     unshuffle=unshuffle)
+                     unshuffle=unshuffle, groups=groups)
 
 
 def transpose_affine(x, to_nchw: bool, scale, shift=None):
@@ -779,15 +818,17 @@ def maxpool_relu_bwd(g, y):
 
 
 def conv_dgrad_bwdstats(dy, wd, cout, ksize, epi_y, residual=None, epi_scale=None, epi_shift=None, epi_slope=None,
-                        epi_slope_const=0.0, epi_act=0):
+                        epi_slope_const=0.0, epi_act=0, grp=0):
     """Stride-1 data-gradient g = conv(dy, wd) (+ residual) that also returns the BN/activation backward partials of g
     against epi_y ([mtiles,3,cout], the layout bwd_finalize consumes)."""
     B, H, W, cin = dy.shape
     g = _f32(B, H, W, cout, like=dy)
     if residual is None and conv_pipe_tw(B, H, W, cin, cout, ksize, 1):
         _, _, _, partial = _conv_pipe(dy, wd, g, cout, ksize, 1, epi=dict(y=epi_y, scale=epi_scale, shift=epi_shift, slope=epi_slope,
-                                                                         slope_const=epi_slope_const, act=epi_act))
+                                                                         slope_const=epi_slope_const, act=epi_act), grp=grp)
         return g, partial
+    if grp and grp < B and epi_scale is not None:
+        raise _abi.HipPathError("conv_dgrad_bwdstats: coefficient groups need the pipelined kernel")
     mt = _abi.lib().sst_conv_stat_tiles(B, H, W, cin, cout, ksize, 1)
     partial = _f32(mt, 3, cout, like=dy)
     args = (ptr(dy), ptr(wd), ptr(g), ptr(residual), ptr(epi_y), ptr(epi_scale), ptr(epi_shift), ptr(epi_slope),
@@ -803,11 +844,11 @@ def conv_dgrad_bwdstats(dy, wd, cout, ksize, epi_y, residual=None, epi_scale=Non
 
 
 def bwd_finalize_apply(part, g, y, n, g2=None, scale=None, shift=None, slope=None, slope_const=0.0, act=0, mean=None, rstd=None,
-                       gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False):
+                       gamma=None, dgamma=None, dbeta=None, dslope=None, accumulate=False, unshuffle=False, groups=1):
     """bwd_reduce_apply with the reduction already done (partials from conv_dgrad_bwdstats)."""
-    cA, cB, cC = bwd_finalize(part, n, mean, rstd, gamma, dgamma, dbeta, dslope, accumulate)
+    cA, cB, cC = bwd_finalize(part, n, mean, rstd, gamma, dgamma, dbeta, dslope, accumulate, groups=groups)
     return bwd_apply(g, y, g2=g2, scale=scale, shift=shift, slope=slope, slope_const=slope_const, act=act, cA=cA, cB=cB, cC=cC,
-                     unshuffle=unshuffle)
+                     unshuffle=unshuffle, groups=groups)
 
 
 def conv_dgrad_fused(g, y2, wd, cout, ksize, cA=None, cB=None, cC=None, in_scale=None, in_shift=None, in_slope=None,
@@ -848,16 +889,33 @@ def flat_layout(params):
 def flat_grads(module, names, params):
     """One flat fp32 buffer + per-parameter views (reference order).  The buffer is remembered on the module so that
     the data-parallel exchange can all-reduce it in place as ONE message (no flatten / unflatten copies) and the flat
-    Adam (srganst.optim.FlatAdam) can consume it as one array."""
+    Adam (srganst.optim.FlatAdam) can consume it as one array.
+    The buffers are PERSISTENT: a ring of FLAT_RING zero-initialised buffers per module, allocated at the first call (always an eager
+    warm-up call: never inside a graph capture) and handed out in turn.  The pad words between the views (flat_layout) are written by
+    nobody, so they stay zero for good - they travel through the flat Adam and the all-reduce with the real gradients, and an
+    uninitialised NaN there would poison any norm / isfinite check over the flat buffer.  A buffer comes round again after
+    FLAT_RING - 1 other backward passes of the module (at most two per step are alive at once: the two-stream discriminator step)."""
     offs, total = flat_layout(params)
-    flat = torch.empty(total, device=params[0].device, dtype=torch.float32)      # pad words are never read by anyone who cares
+    dev = params[0].device
+    ring = module.__dict__.get("_flat_ring")
+    if ring is None or ring["total"] != total or ring["device"] != dev:
+        if torch.cuda.is_current_stream_capturing():
+            raise _abi.HipPathError("flat_grads: the gradient buffers must exist before a graph capture (run an eager warm-up step first)")
+        ring = {"total": total, "device": dev, "next": 0,
+                "bufs": [torch.zeros(total, device=dev, dtype=torch.float32) for _ in range(FLAT_RING)]}
+        module.__dict__["_flat_ring"] = ring
+    flat = ring["bufs"][ring["next"]]
+    ring["next"] = (ring["next"] + 1) % FLAT_RING
     views = {n: flat[o:o + t.numel()].view(t.shape) for n, t, o in zip(names, params, offs)}
-    # remember the last few buffers: with two backward passes per step (D on gt and on sr) autograd accumulates into the
+    # remember the order of use: with two backward passes per step (D on gt and on sr) autograd accumulates into the
     # FIRST pass's buffer, which is then the one holding p.grad
     lst = module.__dict__.setdefault("_flat_grads", [])
-    lst.append(flat)
+    lst[:] = [t for t in lst if t is not flat] + [flat]
     del lst[:-4]
     return views
+
+
+FLAT_RING = 4
 
 
 def flatten_params(module):

@@ -68,6 +68,25 @@ class FlatAdam(torch.optim.Adam):
         return None
 
     @torch.no_grad()
+    def step_params(self, i0, i1, flat_grad=None):
+        """The update of parameters i0 .. i1-1 (named_parameters order) only - the same arithmetic as step() on that slice of the flat
+        buffers; their step counters tick with it.  engine.TrainEngine runs the discriminator's classifier (80 % of its parameters)
+        as soon as its gradient is complete and the generator's backward has read the weights, the feature stack at the end.
+        flat_grad: the flat gradient buffer when p.grad is not assigned yet."""
+        g = flat_grad if flat_grad is not None else self._flat_grad()
+        grp = self.param_groups[0]
+        if g is None or len(self.param_groups) != 1 or grp.get("amsgrad") or grp.get("maximize"):
+            raise RuntimeError("FlatAdam.step_params needs the flat gradient layout (one parameter group, no amsgrad / maximize)")
+        lr = grp["lr"]
+        if not isinstance(lr, torch.Tensor):
+            self._lr_dev.fill_(float(lr))
+            lr = self._lr_dev
+        a = self._offs[i0]
+        b = self._offs[i1] if i1 < len(self._offs) else self._flat_p.numel()
+        b1, b2 = grp["betas"]
+        ops.adam_flat(self._flat_p[a:b], g[a:b], self._m[a:b], self._v[a:b], lr, self._steps[i0:i1], b1, b2, grp["eps"], grp["weight_decay"])
+
+    @torch.no_grad()
     def step(self, closure=None):
         g = self._flat_grad()
         grp = self.param_groups[0]

@@ -72,3 +72,27 @@ def oracle_grads(forward_loss, sd, dtype, inputs=()):
     loss, rest = (out[0], out[1:]) if isinstance(out, tuple) else (out, ())
     loss.backward()
     return loss.detach(), {k: sd[k].grad for k in keys}, [t.grad for t in ins], [r.detach() for r in rest]
+
+
+@pytest.fixture(autouse=True)
+def _sst_env_switches(monkeypatch):
+    """libsrganst.so reads each SST_* dev switch from the environment ONCE (csrc/api.hip: sst_env); tests toggle them with
+    monkeypatch.setenv / delenv, so the library's table is dropped at the start of every test (the previous test's values were
+    restored after its body) and after every change made through monkeypatch."""
+    def reload():
+        mod = sys.modules.get("srganst._abi")
+        if mod is not None:
+            mod.reload_env()
+    reload()
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_reload(name, value, prepend=None):
+        setenv(name, value, prepend)
+        reload()
+
+    def delenv_reload(name, raising=True):
+        delenv(name, raising)
+        reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv_reload, delenv_reload
+    yield
+    reload()

@@ -1,0 +1,241 @@
+"""GPU: several passes of the discriminator batched as ONE tall image with per-pass train-mode BatchNorm statistics (coefficient
+groups: csrc/conv_pipe.hip, bn_elem.hip, conv_wgrad.hip; srganst/disc_graph.py forward on a list of inputs) - the discriminator
+step's D(gt) and D(sr.detach()) of reference train.py:155-158.  Every grouped kernel against the same kernel run pass by pass, the
+batched discriminator against two sequential passes, the batched iteration against the sequential one."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from srganst import ops
+    return ops
+
+
+def _rand(gen, *shape):
+    return torch.randn(*shape, generator=gen).cuda()
+
+
+@pytest.mark.parametrize("case", [(16, 24, 24, 128, 128, 1), (16, 24, 24, 128, 128, 2), (8, 12, 12, 256, 512, 1), (16, 6, 6, 512, 512, 1),
+                                  (8, 48, 48, 64, 64, 2)])
+def test_conv_pipe_groups_vs_pass_by_pass(ops, case):
+    """Forward conv with input affine + LeakyReLU + output statistics over 2 passes of gB images as one batch == the same kernel on
+    each pass with its own coefficient row (same values up to the K-split order of the two launch plans); bn_finalize on the grouped
+    statistics == pass by pass, running statistics moved in pass order."""
+    gB, H, W, cin, cout, stride = case
+    gen = torch.Generator().manual_seed(5)
+    x = _rand(gen, 2 * gB, H, W, cin)
+    w = _rand(gen, cout, cin, 3, 3) / (cin * 9) ** 0.5
+    sc, sh = torch.rand(2, cin, generator=gen).cuda() + 0.5, _rand(gen, 2, cin) * 0.1
+    gam, bet = torch.rand(cout, generator=gen).cuda() + 0.5, _rand(gen, cout)
+    wp = ops.pack_conv(w)
+    assert ops.conv_pipe_groups_ok(2 * gB, H, W, cin, cout, 3, stride, gB)
+    y, _, st, cnt = ops.conv_fwd(x, wp, cout, 3, stride, in_scale=sc, in_shift=sh, in_slope_const=0.2, in_act=1, want_stats=True, grp=gB)
+    rm, rv = torch.zeros(cout).cuda(), torch.ones(cout).cuda()
+    mean, rstd, scale, shift = ops.bn_finalize(st, cnt, gam, bet, rm, rv, groups=2)
+    rm1, rv1 = torch.zeros(cout).cuda(), torch.ones(cout).cuda()
+    for g in range(2):
+        y1, _, st1, cnt1 = ops.conv_fwd(x[g * gB:(g + 1) * gB], wp, cout, 3, stride, in_scale=sc[g], in_shift=sh[g], in_slope_const=0.2,
+                                        in_act=1, want_stats=True)
+        assert rel_err(y[g * gB:(g + 1) * gB], y1) < 2e-6
+        m1, r1, s1, h1 = ops.bn_finalize(st1, cnt1, gam, bet, rm1, rv1)
+        for a, b in ((mean[g], m1), (rstd[g], r1), (scale[g], s1), (shift[g], h1)):
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-6)
+    assert torch.allclose(rm, rm1, rtol=2e-5, atol=2e-6) and torch.allclose(rv, rv1, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", [(16, 24, 24, 128), (8, 12, 12, 256), (16, 6, 6, 512)])
+def test_bn_backward_groups_vs_pass_by_pass(ops, case):
+    """bwd_reduce / bwd_finalize / bwd_apply on two stacked passes == pass by pass (dy bit for bit: same arithmetic per row), with
+    dgamma / dbeta = first pass + second pass (the accumulate flag's fl(a + b))."""
+    gB, H, W, C = case
+    gen = torch.Generator().manual_seed(6)
+    g, y = _rand(gen, 2 * gB, H, W, C), _rand(gen, 2 * gB, H, W, C)
+    gam = torch.rand(C, generator=gen).cuda() + 0.5
+    mean, rstd = _rand(gen, 2, C) * 0.1, torch.rand(2, C, generator=gen).cuda() + 0.5
+    scale = gam * rstd
+    shift = _rand(gen, 2, C) * 0.1
+    n = gB * H * W
+    dg, db = torch.empty(C).cuda(), torch.empty(C).cuda()
+    dy = ops.bwd_reduce_apply(g, y, n, scale=scale, shift=shift, slope_const=0.2, act=1, mean=mean, rstd=rstd, gamma=gam, dgamma=dg, dbeta=db,
+                              groups=2)
+    dg1, db1 = torch.empty(C).cuda(), torch.empty(C).cuda()
+    for k in range(2):
+        sl = slice(k * gB, (k + 1) * gB)
+        dy1 = ops.bwd_reduce_apply(g[sl], y[sl], n, scale=scale[k], shift=shift[k], slope_const=0.2, act=1, mean=mean[k], rstd=rstd[k],
+                                   gamma=gam, dgamma=dg1, dbeta=db1, accumulate=k > 0)
+        assert torch.equal(dy[sl], dy1)
+    assert torch.equal(dg, dg1) and torch.equal(db, db1)
+    # bias-only layer (no BatchNorm): dbeta = column sums of gz over both passes
+    dbb, dbb1 = torch.empty(C).cuda(), torch.empty(C).cuda()
+    dy = ops.bwd_reduce_apply(g, y, n, slope_const=0.2, act=1, dbeta=dbb, groups=2)
+    for k in range(2):
+        sl = slice(k * gB, (k + 1) * gB)
+        dy1 = ops.bwd_reduce_apply(g[sl], y[sl], n, slope_const=0.2, act=1, dbeta=dbb1, accumulate=k > 0)
+        assert torch.equal(dy[sl], dy1)
+    assert torch.equal(dbb, dbb1)
+
+
+@pytest.mark.parametrize("case", [(8, 24, 24, 128, 128, 1), (8, 24, 24, 128, 128, 2), (8, 12, 12, 256, 512, 1), (8, 96, 96, 64, 64, 2)])
+def test_conv_wgrad_groups_vs_pass_by_pass(ops, case):
+    gB, H, W, cin, cout, stride = case
+    gen = torch.Generator().manual_seed(7)
+    ho, wo = ops.conv_out_hw(H, W, 3, stride)
+    x, dy = _rand(gen, 2 * gB, H, W, cin), _rand(gen, 2 * gB, ho, wo, cout)
+    sc, sh = torch.rand(2, cin, generator=gen).cuda() + 0.5, _rand(gen, 2, cin) * 0.1
+    assert ops._abi.lib().sst_conv_wgrad_groups_ok(2 * gB, H, W, cin, cout, 3, stride, gB)
+    dw = torch.empty(cout, cin, 3, 3).cuda()
+    ops.conv_wgrad(x, dy, dw, 3, stride, in_scale=sc, in_shift=sh, in_slope_const=0.2, in_act=1, grp=gB)
+    dw1 = torch.empty_like(dw)
+    for k in range(2):
+        sl = slice(k * gB, (k + 1) * gB)
+        ops.conv_wgrad(x[sl], dy[sl], dw1, 3, stride, in_scale=sc[k], in_shift=sh[k], in_slope_const=0.2, in_act=1, accumulate=k > 0)
+    assert rel_err(dw, dw1) < 2e-6
+
+
+def test_dgrad_epilogue_partials_and_flatten_groups(ops):
+    gB, H, W, cin, cout = 16, 24, 24, 256, 128          # data-gradient of a 128 -> 256 layer: dy has 256 channels, g has 128
+    gen = torch.Generator().manual_seed(8)
+    dy, yprev = _rand(gen, 2 * gB, H, W, cin), _rand(gen, 2 * gB, H, W, cout)
+    w = _rand(gen, cin, cout, 3, 3) / (cout * 9) ** 0.5
+    wd = ops.pack_conv(w, mode=1)
+    sc, sh = torch.rand(2, cout, generator=gen).cuda() + 0.5, _rand(gen, 2, cout) * 0.1
+    g, part = ops.conv_dgrad_bwdstats(dy, wd, cout, 3, yprev, epi_scale=sc, epi_shift=sh, epi_slope_const=0.2, epi_act=1, grp=gB)
+    nt = part.shape[0] // 2
+    for k in range(2):
+        sl = slice(k * gB, (k + 1) * gB)
+        g1, p1 = ops.conv_dgrad_bwdstats(dy[sl], wd, cout, 3, yprev[sl], epi_scale=sc[k], epi_shift=sh[k], epi_slope_const=0.2, epi_act=1)
+        assert rel_err(g[sl], g1) < 2e-6
+        assert p1.shape[0] == nt and rel_err(part[k * nt:(k + 1) * nt].sum(0), p1.sum(0)) < 1e-5
+    y = _rand(gen, 2 * gB, 6, 6, 64)
+    s2, h2 = torch.rand(2, 64, generator=gen).cuda() + 0.5, _rand(gen, 2, 64)
+    flat = ops.flatten_act(y, s2, h2, 0.2, 1, grp=gB)
+    for k in range(2):
+        sl = slice(k * gB, (k + 1) * gB)
+        assert torch.equal(flat[sl], ops.flatten_act(y[sl], s2[k], h2[k], 0.2, 1))
+
+
+def _make_d(seed=3):
+    from srganst.config import Config
+    from srganst.model import Discriminator
+    cfg = Config()
+    torch.manual_seed(seed)
+    return cfg, Discriminator(cfg).cuda().train()
+
+
+def test_discriminator_two_passes_as_one_batch():
+    """disc_graph.forward on [a, b] (one tall image, per-pass statistics) + ONE backward over 2B images against two sequential passes
+    (second one accumulating): logits, every saved coefficient row, running statistics / counters, every parameter gradient."""
+    from srganst import disc_graph, ops
+    B = 8
+    gen = torch.Generator().manual_seed(9)
+    a, b = torch.rand(B, 3, 96, 96, generator=gen).cuda(), torch.rand(B, 3, 96, 96, generator=gen).cuda()
+    dl = _rand(gen, 2 * B, 1) / B
+    outs = {}
+    for mode in ("seq", "batched"):
+        cfg, D = _make_d()
+        names = [n for n, _ in D.named_parameters()]
+        pd = dict(zip(names, [t.detach() for t in D.parameters()]))
+        if mode == "batched":
+            assert disc_graph.groups_supported(D, pd, B, 2, 96, 96)
+            pred, sv = disc_graph.forward(D, [a, b], pd, True, True)
+            grads, _ = disc_graph.backward(D, pd, sv, dl, True, False)
+            rows = [(r["scale"], r["shift"]) for r in sv["layers"] if r["bi"] is not None]
+        else:
+            pa, sva = disc_graph.forward(D, a, pd, True, True)
+            pb, svb = disc_graph.forward(D, b, pd, True, True)
+            pred = torch.cat([pa, pb])
+            D.__dict__["_grad_accum"] = {"flat": None}
+            grads, _ = disc_graph.backward(D, pd, sva, dl[:B].contiguous(), True, False)
+            disc_graph.backward(D, pd, svb, dl[B:].contiguous(), True, False)
+            D.__dict__.pop("_grad_accum")
+            rows = [(torch.stack([ra["scale"], rb["scale"]]), torch.stack([ra["shift"], rb["shift"]]))
+                    for ra, rb in zip(sva["layers"], svb["layers"]) if ra["bi"] is not None]
+        torch.cuda.synchronize()
+        outs[mode] = (pred.clone(), {n: g.clone() for n, g in grads.items()}, {k: v.clone() for k, v in D.state_dict().items()}, rows)
+    ps, gs, sds, rs = outs["seq"]
+    pb_, gb, sdb, rb_ = outs["batched"]
+    assert rel_err(pb_, ps) < 1e-5
+    for (s1, h1), (s2, h2) in zip(rs, rb_):
+        assert torch.allclose(s1, s2, rtol=1e-4, atol=1e-6) and torch.allclose(h1, h2, rtol=1e-4, atol=1e-5)
+    for k in sds:
+        if "running" in k or "num_batches" in k:
+            assert torch.allclose(sds[k].float(), sdb[k].float(), rtol=1e-5, atol=1e-6), k
+    assert int(sdb["features.3.num_batches_tracked"]) == 2
+    worst = max((rel_err(gb[n], gs[n]), n) for n in gs)
+    print("worst gradient difference batched vs sequential:", worst)
+    assert worst[0] < 2e-4, worst
+
+
+def test_train_iteration_batched_d_step_matches_sequential():
+    """The whole iteration (engine.TrainEngine, merged schedule, three discriminator forwards) with the discriminator step's two passes
+    as one batch (KERNEL.BATCH_D_STEP) against the same schedule pass by pass.  The discriminator's gradients are ill-conditioned in
+    fp32 (BatchNorm backward subtracts nearly all of its input: two fp32 evaluations in different summation orders differ by ~1e-3,
+    as the reference's own fp32 run does from fp64 - DESIGN.md section 2), so the yardstick is the fp64 truth: the batched step's
+    distance from oracle/ run in fp64 on the same sr / gt must be within max(1e-3, 3 x the pass-by-pass schedule's own distance).
+    Forward-side quantities (d_loss, logits, BatchNorm buffers) are held to 1e-5 directly; hipGraph replay must reproduce the eager
+    batched run bit for bit over 4 iterations."""
+    import torch.nn.functional as F
+    from conftest import assert_fp64_truth
+    from oracle import model as om
+    from srganst.config import Config
+    from srganst.engine import TrainEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+
+    def run(batched, use_graph, steps):
+        cfg = Config()
+        cfg.MODEL.G_N_RCB = 2
+        cfg.KERNEL.REUSE_D_SR, cfg.KERNEL.BATCH_D_STEP = False, batched
+        torch.manual_seed(1)
+        D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
+        d0 = {k: v.detach().clone().cpu() for k, v in D.state_dict().items()}
+        cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+        cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+        cfg.SOLVER.D_UPDATE_INTERVAL = 1
+        eng = TrainEngine(cfg, G, D, use_graph=use_graph, adam_capturable=True)
+        gen = torch.Generator().manual_seed(2)
+        for _ in range(steps):
+            gt = torch.rand(8, 3, 96, 96, generator=gen)
+            eng.step(gt.cuda(), torch.rand(8, 3, 24, 24, generator=gen).cuda())
+        torch.cuda.synchronize()
+        assert eng.graph_active == use_graph and eng.d_batched == batched
+        sd = {"G." + k: v.clone() for k, v in G.state_dict().items()}
+        sd.update({"D." + k: v.clone() for k, v in D.state_dict().items()})
+        sd["d_loss"], sd["pred_gt"], sd["pred_sr"] = eng.d_loss.clone(), eng.pred_gt.clone(), eng.pred_sr.clone()
+        grads = {n: p.grad.detach().clone().cpu() for n, p in D.named_parameters()}
+        sr = eng.sr.clone().cpu()
+        eng.close()
+        return sd, grads, sr, gt, d0
+
+    out4, _, _, _, _ = run(True, False, 4)
+    outg, _, _, _, _ = run(True, True, 4)
+    for k in out4:
+        assert torch.equal(out4[k], outg[k]), ("graph replay differs from eager", k)
+    assert int(out4["D.features.3.num_batches_tracked"]) == 12
+
+    ref, g_seq, sr_seq, gt, d0 = run(False, False, 1)
+    out, g_bat, sr_bat, _, _ = run(True, False, 1)
+    assert torch.equal(sr_seq, sr_bat)                       # the generator step is the same launches in both schedules
+    for k in ("d_loss", "pred_gt", "pred_sr"):
+        assert rel_err(out[k], ref[k]) < 1e-5, k
+    for k in ref:
+        if k.startswith("D.") and ("running" in k or "num_batches" in k):
+            assert torch.allclose(ref[k].float(), out[k].float(), rtol=1e-5, atol=1e-6), k
+    # fp64 truth of the discriminator step on the same inputs (train.py:155-161)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in d0.items()}
+    for k in om.param_keys(sd64):
+        sd64[k].requires_grad_(True)
+    # (D's BatchNorm buffers have moved once by the generator step's D(sr); train-mode gradients do not depend on them)
+    l = F.binary_cross_entropy_with_logits(om.discriminator_forward(sd64, gt.double(), True, {}), torch.full((8, 1), 0.9, dtype=torch.float64)) + \
+        F.binary_cross_entropy_with_logits(om.discriminator_forward(sd64, sr_seq.double(), True, {}), torch.zeros(8, 1, dtype=torch.float64))
+    l.backward()
+    report = []
+    for n in g_seq:
+        assert_fp64_truth("D." + n, g_bat[n], g_seq[n], sd64[n].grad, report)
+    worst = max(report, key=lambda r: r[1])
+    print(f"worst batched-step gradient error against fp64: {worst[0]} {worst[1]:.2e} (pass-by-pass schedule: {worst[2]:.2e})")
