@@ -102,6 +102,14 @@ class Config:
         self.DIST.BACKEND = "nccl"          # RCCL on ROCm; "gloo" in the CPU tests
         self.DIST.BUCKET_D = True           # D grads in two buckets (features / classifier)
         self.DIST.OVERLAP_COMM = True       # hide the gradient all-reduces behind compute (engine.TrainEngine._step_overlapped)
+        # RCCL only: the mean-all-reduces are captured INSIDE the iteration's hipGraph (the process group's stream forks from the branch that
+        # produced the bucket and is joined into the graph's origin stream) - the iteration stays ONE graph at N > 1.  Off / gloo: the
+        # graphs are cut where a collective goes out (_step_overlapped)
+        # OFF: built, bit-identical to the cut-graph schedule (tests/test_dp_gpu.py, RCCL world 1), but measured SLOWER on ROCm 7.2: as
+        # soon as the graph holds the collectives' nodes the runtime runs its two compute branches one after the other (device stamps:
+        # the generator's backward starts when the discriminator branch has ended) - 5.80 ms against 5.20 ms for the cut graphs and
+        # 4.97 ms single-process (tools/time_dp.py, three discriminator forwards)
+        self.DIST.ONE_GRAPH = os.environ.get("SST_DP_ONE_GRAPH", "0") != "0"
         self.KERNEL = dotdict()
         self.KERNEL.USE_GRAPH = True        # capture the train step into a hipGraph
         self.KERNEL.SYNC_LOSS_EVERY_STEP = False  # reference does .item() per criterion per step (train.py:141)

@@ -37,6 +37,11 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, local, world
 
 
+def is_rccl(pg=None) -> bool:
+    """True when gradients travel over RCCL (backend "nccl"): its collectives can be captured into a hipGraph."""
+    return td.is_available() and td.is_initialized() and td.get_backend(pg) == "nccl"
+
+
 def world_size(pg=None) -> int:
     return td.get_world_size(pg) if td.is_available() and td.is_initialized() else 1
 

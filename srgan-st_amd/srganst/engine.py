@@ -174,7 +174,13 @@ class WarmupEngine:
         self.loss_values = OrderedDict()
         self.sr = None
         self.dp = self.world > 1 or force_dp     # force_dp: run the split-graph + collective path even with one rank (tests)
-        if self.dp:             # collective stays outside the graph: [fwd+bwd graph] -> all-reduce -> [optimizer]
+        # RCCL: the all-reduce is captured inside the step's graph (DIST.ONE_GRAPH); otherwise it stays outside:
+        # [fwd+bwd graph] -> all-reduce -> [optimizer]
+        self.one_graph_dp = self.dp and sdist.is_rccl(process_group) and bool(config.DIST.ONE_GRAPH)
+        if self.one_graph_dp:
+            self._fb = _GraphedStep(self._full_step_dp, enabled=use_graph, on_fail=self._drop_graphs)
+            self._op = None
+        elif self.dp:
             self._fb = _GraphedStep(self._fwd_bwd, enabled=use_graph, on_fail=self._drop_graphs)
             self._op = _GraphedStep(self._opt_step, enabled=use_graph, on_fail=self._drop_graphs)
         else:
@@ -212,6 +218,15 @@ class WarmupEngine:
         self.opt.step()
         return vals
 
+    def _full_step_dp(self):
+        vals = self._fwd_bwd()
+        ar = sdist.AsyncAllReduce(sdist.module_flat_grad(self.G), self.pg, force=True)      # forks from / joins this (the origin) stream
+        if ar.flat is None:
+            sdist.allreduce_module_grads(self.G, self.pg, force=True)
+        ar.wait()
+        self.opt.step()
+        return vals
+
     def close(self):
         """Drop the captured graphs and static buffers (also breaks the engine <-> bound-method reference cycle, so the
         device objects are released right here and not by a later cyclic collection)."""
@@ -222,7 +237,7 @@ class WarmupEngine:
         """One optimisation step on the batch (gt [B,3,H,W], lr [B,3,H/4,W/4], device tensors)."""
         _load_inputs(self, gt, lr)
         self._fb()
-        if self.dp:
+        if self.dp and not self.one_graph_dp:
             sdist.allreduce_module_grads(self.G, self.pg, force=True)
             self._op()
         return self.loss_values
@@ -264,12 +279,23 @@ class TrainEngine:
         # generator's message travels under the first of those graphs.  overlap_comm=False: the round-1 schedule
         # ([fwd+bwd] -> all-reduce -> wait -> [Adam] per network); both give bit-identical parameters (tests/test_dp_gpu.py).
         self.overlap = self.dp and (config.DIST.OVERLAP_COMM if overlap_comm is None else overlap_comm)
+        # ... and with RCCL the collectives are captured inside the merged iteration graph (_iter_gd): ONE graph per iteration at N > 1
+        # as at N = 1.  (What hipStreamEndCapture accepts decides the shape: a collective issued on the side branch runs on the process
+        # group's stream, a SECOND-level fork, which may only be joined into the graph's origin stream - see _iter_gd.)
+        self.one_graph_dp = (self.overlap and sdist.is_rccl(process_group) and bool(config.DIST.ONE_GRAPH)
+                             and bool(getattr(config.KERNEL, "OVERLAP_GD", False)))
+        if self.one_graph_dp:
+            self.overlap = False
         self._d_a = self._d_b = self._g_f = self._g_b = None
         self.d_batched = False           # set once the discriminator step has run its two passes as one batch (KERNEL.BATCH_D_STEP)
         self.d_sr_reused = False         # set once the discriminator step has run on the generator step's D(sr) pass (KERNEL.REUSE_D_SR)
         self._side = self._side_d = None
         self._it = None
-        if self.dp:
+        if self.one_graph_dp:
+            self._g_fb, self._g_op = _GraphedStep(self._g_full, enabled=g, on_fail=f), None
+            self._d_fb = self._d_op = None
+            self._it = _GraphedStep(self._iter_gd, enabled=g, on_fail=f)
+        elif self.dp:
             self._g_fb, self._g_op = _GraphedStep(self._g_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self.g_opt.step, enabled=g, on_fail=f)
             self._d_fb, self._d_op = _GraphedStep(self._d_fwd_bwd, enabled=g, on_fail=f), _GraphedStep(self._d_step, enabled=g, on_fail=f)
             if self.overlap:
@@ -350,8 +376,17 @@ class TrainEngine:
     def _g_bwd(self):
         self._g_total.backward(_one(self._g_total))
 
+    def _g_allreduce(self):
+        """Mean of the generator's gradient over the ranks, issued from (and joined into) the current stream; capturable with RCCL."""
+        ar = sdist.AsyncAllReduce(sdist.module_flat_grad(self.G), self.pg, force=True)
+        if ar.flat is None:                                      # gradients not in one flat buffer: the generic path
+            sdist.allreduce_module_grads(self.G, self.pg, force=True)
+        ar.wait()
+
     def _g_full(self):
         v = self._g_fwd_bwd()
+        if self.one_graph_dp:
+            self._g_allreduce()
         self.g_opt.step()
         return v
 
@@ -585,12 +620,17 @@ class TrainEngine:
             ops.debug_stamp(3)
             self._d_fwd_cls(early_gt)           # streams, as _d_two_stream does on its own) crashed hipStreamEndCapture (ROCm 7.2)
             ops.debug_stamp(4)
+            # data parallel, one graph: the classifier bucket (75.5 MB) goes out now, under the feature stack's backward.  The
+            # collective runs on the process group's own stream - forked from this side stream, i.e. a second-level fork: its
+            # wait() below is issued on `main`, the capture's origin stream (a second-level stream joined into a first-level one
+            # is what crashes hipStreamEndCapture).
+            ar_c = sdist.AsyncAllReduce(self._d_buckets[0], self.pg, force=True) if self.one_graph_dp else None
         # D's Adam in two parts (KERNEL.SPLIT_D_ADAM): the classifier's gradient is complete here; its weights are read once more,
         # by the head of the generator's backward (through D), which hands over with an event - then the classifier's update runs on
         # the side stream beside the rest of both branches and only the feature stack's (4.7 M parameters) is left for the join.
         names = [n for n, _ in self.D.named_parameters()]
         cls0 = names.index("classifier.0.weight")
-        split = bool(cfg.KERNEL.SPLIT_D_ADAM) and self._d_flat is not None and hasattr(self.d_opt, "step_params")
+        split = bool(cfg.KERNEL.SPLIT_D_ADAM) and not self.dp and self._d_flat is not None and hasattr(self.d_opt, "step_params")
 
         def cls_adam():
             ev = torch.cuda.Event()
@@ -611,11 +651,15 @@ class TrainEngine:
             self.D.__dict__.pop("_after_cls_bwd", None)
         ops.debug_stamp(7)
         self.loss_values = vals
+        if self.one_graph_dp:
+            self._g_allreduce()                 # 6.2 MB, behind the classifier bucket on the process group's stream
         self.g_opt.step()
         ops.debug_stamp(8)
         with torch.cuda.stream(side):           # (issued after the generator's backward: the classifier's Adam sits in front of it)
-            deferred = [] if cfg.KERNEL.DEFER_D_WGRAD else None
+            # (data parallel: nothing is deferred - the feature bucket goes out right behind this call and must be complete)
+            deferred = [] if (cfg.KERNEL.DEFER_D_WGRAD and not self.dp) else None
             self._d_features(deferred)
+            ar_f = sdist.AsyncAllReduce(self._d_buckets[1], self.pg, force=True) if self.one_graph_dp else None
             ops.debug_stamp(5)
         # The side branch is the longer one (D(gt) forward + two backward passes against one generator backward).  The conv weight
         # gradients of its last pass are leaves of that chain: they run HERE, on the generator's stream, which would otherwise idle
@@ -630,6 +674,9 @@ class TrainEngine:
                         t.record_stream(main)   # is destroyed after the capture, left the allocator with a dangling stream (segfaults in later replays)
             launch()
         main.wait_stream(self._side_d)
+        if self.one_graph_dp:
+            ar_c.wait()                          # on the origin stream
+            ar_f.wait()
         if split:
             self.d_opt.step_params(0, cls0, flat_grad=self._d_flat)
             self.D.__dict__["_packs_fresh"] = False      # weights changed

@@ -131,17 +131,19 @@ def _nccl_worker(port, q):
     # the full G + D step (train.py:100-164): [G fwd+bwd graph] -> all-reduce -> [G Adam] -> [D fwd+bwd graph] -> 2-bucket all-reduce -> [D Adam]
     from srganst.engine import TrainEngine
     from srganst.model import Discriminator
-    # single graphs / split graphs with blocking collectives (round-1 schedule) / overlapped schedule (default): the two D
-    # buckets and G's message are in flight on RCCL's stream while the next graphs run
-    for force_dp, overlap in ((False, False), (True, False), (True, True)):
+    # single graphs / split graphs with blocking collectives (round-1 schedule) / overlapped schedule with the graphs cut where a
+    # collective goes out (the two D buckets and G's message in flight on RCCL's stream while the next graphs run) / the default with
+    # RCCL: ONE graph per iteration with the three collectives captured inside it (DIST.ONE_GRAPH)
+    for force_dp, overlap, one_graph in ((False, False, True), (True, False, True), (True, True, False), (True, True, True)):
         cfg, G = _make(seed=6)
+        cfg.DIST.ONE_GRAPH = one_graph
         cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
         cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
         cfg.SOLVER.D_UPDATE_INTERVAL = 1
         torch.manual_seed(7)
         D = Discriminator(cfg).to("cuda:0").train()
         eng = TrainEngine(cfg, G, D, use_graph=True, adam_capturable=True, force_dp=force_dp, overlap_comm=overlap)
-        assert eng.overlap == overlap
+        assert eng.one_graph_dp == (force_dp and overlap and one_graph) and eng.overlap == (overlap and not eng.one_graph_dp)
         for step in range(4):
             g = torch.Generator().manual_seed(50 + step)           # the discriminator is fixed to 96 x 96 inputs (model.py:31-34)
             eng.step(torch.rand(2, 3, 96, 96, generator=g).cuda(), torch.rand(2, 3, 24, 24, generator=g).cuda())
@@ -163,14 +165,15 @@ def test_graph_capture_next_to_rccl_communicator():
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
     p.start()
-    a, b, c, d, e = q.get(timeout=300)
+    a, b, c, d, e, f = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0
     for k in a:
-        assert (a[k] == b[k]).all(), k
+        assert (a[k] == b[k]).all(), k           # SRResNet step: all-reduce captured inside the step's graph == single-process graph
     for k in c:
         assert (c[k] == d[k]).all(), k
-        assert (c[k] == e[k]).all(), k           # overlapped collectives: bit-identical to the single-graph step
+        assert (c[k] == e[k]).all(), k           # overlapped collectives between cut graphs: bit-identical to the single-graph step
+        assert (c[k] == f[k]).all(), k           # collectives captured inside the ONE iteration graph: bit-identical too
 
 
 def _train_worker(rank, world, port, overlap, q):

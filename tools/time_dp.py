@@ -19,8 +19,11 @@ td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda
 dev = torch.device("cuda", 0)
 gt, lr = bench.synth_batch(16, 96, dev, 1)
 for name, kw in (("single process, merged graph", dict()), ("dp blocking", dict(force_dp=True, overlap_comm=False)),
-                 ("dp overlapped, two branches", dict(force_dp=True, overlap_comm=True))):
+                 ("dp overlapped, graphs cut at the collectives", dict(force_dp=True, overlap_comm=True, one_graph=False)),
+                 ("dp, ONE graph with captured collectives", dict(force_dp=True, overlap_comm=True))):
     cfg = Config()
+    cfg.DIST.ONE_GRAPH = kw.pop("one_graph", True)
+    cfg.KERNEL.REUSE_D_SR = os.environ.get("SST_REUSE_D_SR", "0") != "0"       # default here: three discriminator forwards, as the bench headline
     torch.manual_seed(0)
     D, G = Discriminator(cfg).to(dev).train(), Generator(cfg).to(dev).train()
     cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
@@ -35,5 +38,9 @@ for name, kw in (("single process, merged graph", dict()), ("dp blocking", dict(
         eng.step(eng.gt, eng.lr)
     torch.cuda.synchronize()
     print(f"{name:32s} {(time.perf_counter() - t0) / 60 * 1e3:.3f} ms / iteration  (graphs active: {eng.graph_active})", flush=True)
+    if os.environ.get("SST_STAMP", "0") != "0":
+        from srganst import ops
+        t = ops.debug_stamps().cpu().tolist()
+        print("   stamps (us): " + "  ".join(f"{i}:{(t[i] - t[0]) / 100.0:.0f}" for i in range(10)), flush=True)
     eng.close()
 td.destroy_process_group()
