@@ -32,6 +32,8 @@ D_FWD_MAC_PER_IMG = 884.15e6
 VGG_FWD_MAC_PER_IMG = 3583.18e6
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
+# kernels of the 3-channel first discriminator layer (model.py:32): on the matrix cores, but one pass over a 37.7 MB tensor each
+STREAMING_3CH = ("conv3_to3_kernel", "wgrad_k3c3_mfma_kernel", "conv3_c3in_mfma_kernel", "conv3_c3in_kernel", "wgrad_k3c3_kernel")
 
 WORKLOADS = {
     # name -> (description, MACs per image per step as multiples of (G fwd, D fwd, VGG fwd))
@@ -137,6 +139,15 @@ def kernel_roofline(workload, device, hr, B):
     for name, calls in trace.items():
         t = _replay_time(calls)
         flops = sum(f for _, f, _ in calls)
+        if name.split("+")[0] in STREAMING_3CH:
+            # 3x3 convs with a 3-channel side (the discriminator's first layer: forward, data-gradient, weight gradient) run on the
+            # matrix cores but are bound by streaming the 64-channel tensor once: priced against HBM.  Algorithmic bytes = the
+            # 64-channel tensor + the 3-channel tensor (B*H*W pixels = flops / (2 * 64 * 27))
+            nbytes = flops / (2.0 * 64 * 27) * (64 + 3) * 4.0
+            rows[name] = {"bound": "hbm", "launches_per_step": len(calls), "avg_launch_us": t / len(calls) * 1e6, "gbs": nbytes / t / 1e9,
+                          "frac": nbytes / t / 1e9 / PEAK_HBM_GBS, "ms_per_step": t * 1e3, "bytes_per_launch": nbytes / len(calls),
+                          "tflops": flops / t / 1e12}
+            continue
         rows[name] = {"bound": "mfma", "launches_per_step": len(calls), "avg_launch_us": t / len(calls) * 1e6, "tflops": flops / t / 1e12,
                       "frac": flops / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, "ms_per_step": t * 1e3, "flop_per_launch": flops / len(calls)}
     for name, calls in hbm.items():
@@ -172,8 +183,10 @@ def kernel_roofline(workload, device, hr, B):
     traffic = None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes
     if os.path.exists(tf):
+        # keyed by the exact configuration the counters were collected on (workload, crop size, batch): a line for another shape
+        # carries null, never another shape's bytes
         try:
-            traffic = json.load(open(tf)).get(workload, {}).get(dom)
+            traffic = json.load(open(tf)).get(f"{workload}_hr{hr}_b{B}", {}).get(dom)
         except Exception:
             traffic = None
     if r["bound"] == "mfma":
@@ -429,7 +442,7 @@ def main():
         wl = workload_name(args.workload, args.hr, B)
         step_kind = {"srgan": "G+D+ST-loss step", "srresnet": "SRResNet G-only mse+ST step", "srgan_vgg": "G+D+VGG+ST-loss step"}[args.workload]
         out = {"metric": f"HR images/sec ({args.hr}px x4, B={B}/GPU) {step_kind}", "value": imgs, "unit": "HR images/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "timed_region_s": el, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl, "global_batch": B * world, "hr": args.hr, "lr": args.hr // 4,
                           "parallelism": f"dp{world}", "comm": comm, "hip_graph": graph_active, "d_update_interval": 1 if args.workload != "srresnet" else None,

@@ -135,6 +135,14 @@ class Config:
         # OFF: measured slower (5.015 vs 4.960 ms, same box): the 75.5 MB classifier's update streams 528 MB through the Infinity Cache
         # while both branches are running and evicts what their conv kernels were re-reading; at the join nothing else runs
         self.KERNEL.SPLIT_D_ADAM = os.environ.get("SST_SPLIT_D_ADAM", "0") != "0"
+        # merged iteration, the other direction: with the discriminator step batched the GENERATOR's branch is the longer one - its
+        # weight gradients (leaves of its backward) run on the discriminator's stream after that branch's work.  Mask: 1 conv3 (9x9),
+        # 2 the up-sampling convs, 4 the grouped trunk launch, 8 conv1 (9x9); 0 = none
+        # OFF: measured slower (5.00 ms with none, 5.26 with the trunk launch moved, 5.76-5.88 with more): the generator's backward does not
+        # get shorter without them (device stamps: it ends at 4.9-5.0 ms either way - its chain of short launches only gets the chip when
+        # the discriminator branch's persistent conv kernels leave it), the moved launches just run after everything else.  Stream
+        # priorities change nothing either (main high: 5.00 ms; side high: 8.55 ms)
+        self.KERNEL.DEFER_G_WGRAD = int(os.environ.get("SST_DEFER_G_WGRAD", "0"))
         self.KERNEL.EARLY_D_PACK = os.environ.get("SST_EARLY_D_PACK", "1") != "0"
         self.KERNEL.REUSE_D_SR = os.environ.get("SST_REUSE_D_SR", "1") != "0"
         # the discriminator step's two passes, D(gt) and D(sr.detach()) (train.py:155-158), as ONE batch of 2B images with per-pass

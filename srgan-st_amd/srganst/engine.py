@@ -21,6 +21,7 @@ import os
 import torch
 
 from . import dist as sdist
+from . import ops as _ops
 
 
 def make_adam(module, lr, betas, eps, weight_decay, capturable):
@@ -126,13 +127,29 @@ class _GraphedStep:
                 # must not invalidate it
                 # a capture stream of its own: torch's shared default capture stream would stay dead for every later capture
                 # of the process once ONE capture on it has been invalidated
-                with torch.cuda.graph(g, stream=torch.cuda.Stream(), capture_error_mode="thread_local"):
-                    self.out = self.fn()
+                cap_stream = torch.cuda.Stream()
+                _ops.TOPOLOGY_ERROR = None
+                _ops.CAPTURE_ORIGIN = cap_stream          # helper-stream joins are checked against it (ops.check_capture_join)
+                try:
+                    with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
+                        self.out = self.fn()
+                finally:
+                    _ops.CAPTURE_ORIGIN = None
                 self.graph = g
                 if dot:
                     g.debug_dump(os.path.join(dot, f"graph_{getattr(self.fn, '__name__', 'fn')}_{id(self):x}.dot"))
             except Exception as e:  # keep training (eager) rather than die: a step is still the same kernels
                 import sys
+                if _ops.TOPOLOGY_ERROR is not None:      # a schedule the runtime cannot capture is a configuration error, not a fallback case
+                    msg, _ops.TOPOLOGY_ERROR = _ops.TOPOLOGY_ERROR, None
+                    torch.cuda.set_stream(launch_stream)
+                    torch.cuda.synchronize()
+                    from . import _abi as _a
+                    _a.lib().sst_clear_error()
+                    self.drop()
+                    if self.on_fail is not None:
+                        self.on_fail()
+                    raise _ops.CaptureTopologyError(msg) from e
                 print(f"[srganst] hipGraph capture failed ({type(e).__name__}: {e}); the whole engine continues in eager mode",
                       file=sys.stderr)
                 # torch.cuda.graph.__exit__ raises from capture_end() BEFORE it leaves its stream context: the current stream
@@ -556,6 +573,7 @@ class TrainEngine:
         st_gt = disc_graph.backward_classifier(D, pd, sv_gt, dl_gt, True)
         g_gt, _ = disc_graph.backward_features(D, pd, sv_gt, st_gt, True, False)
         flat_gt = D.__dict__["_flat_grads"][-1]
+        ops.check_capture_join(main)          # inside the side branch of a merged capture this join is the one the runtime faults on
         main.wait_stream(side)
         flat_sr.add_(flat_gt)                 # autograd order of the sequential path: the D(sr) pass writes, the D(gt) pass accumulates
         self.d_loss, self.pred_gt, self.pred_sr = loss_real + loss_fake, pred_gt, pred_sr
@@ -644,16 +662,23 @@ class TrainEngine:
             else:
                 cls_adam()
         ops.debug_stamp(6)
+        # The generator's weight gradients selected by KERNEL.DEFER_G_WGRAD leave its backward chain and run on the side stream behind
+        # the discriminator step's work (gen_graph.backward hands them over): its Adam then waits for the join.
+        g_def = [] if (int(cfg.KERNEL.DEFER_G_WGRAD) and not self.dp) else None
+        if g_def is not None:
+            self.G.__dict__["_defer_wgrad"] = (g_def, int(cfg.KERNEL.DEFER_G_WGRAD))
         try:
             with torch.autograd.set_multithreading_enabled(False):      # backward on this thread: one thread feeds the open capture
                 total.backward(_one(total))
         finally:
             self.D.__dict__.pop("_after_cls_bwd", None)
+            self.G.__dict__.pop("_defer_wgrad", None)
         ops.debug_stamp(7)
         self.loss_values = vals
         if self.one_graph_dp:
             self._g_allreduce()                 # 6.2 MB, behind the classifier bucket on the process group's stream
-        self.g_opt.step()
+        if not g_def:
+            self.g_opt.step()
         ops.debug_stamp(8)
         with torch.cuda.stream(side):           # (issued after the generator's backward: the classifier's Adam sits in front of it)
             # (data parallel: nothing is deferred - the feature bucket goes out right behind this call and must be complete)
@@ -661,6 +686,13 @@ class TrainEngine:
             self._d_features(deferred)
             ar_f = sdist.AsyncAllReduce(self._d_buckets[1], self.pg, force=True) if self.one_graph_dp else None
             ops.debug_stamp(5)
+            for ev, launch, tensors in (g_def or ()):
+                side.wait_event(ev)
+                if not torch.cuda.is_current_stream_capturing():     # eager: main's allocator must not re-use these blocks before `side` is done
+                    for t in tensors:
+                        if t is not None:
+                            t.record_stream(side)
+                launch()
         # The side branch is the longer one (D(gt) forward + two backward passes against one generator backward).  The conv weight
         # gradients of its last pass are leaves of that chain: they run HERE, on the generator's stream, which would otherwise idle
         # until the join - each behind the event of its dy.  Same kernels, same arguments, same accumulation order per parameter
@@ -674,6 +706,8 @@ class TrainEngine:
                         t.record_stream(main)   # is destroyed after the capture, left the allocator with a dangling stream (segfaults in later replays)
             launch()
         main.wait_stream(self._side_d)
+        if g_def:
+            self.g_opt.step()                    # its last weight gradients came from the side stream
         if self.one_graph_dp:
             ar_c.wait()                          # on the origin stream
             ar_f.wait()

@@ -222,6 +222,20 @@ def backward(module, params, sv, dsr, need_dx=False):
     a1 = p["conv1.1.weight"]
     wd, w9 = sv["wd"], sv["w9"]                  # packed by the forward's multi-tensor launch
     wg = ops.WgradGroup()            # the trunk-shaped weight gradients go out as ONE launch at the end
+    # Weight gradients are leaves of the backward chain.  An owner that runs another branch beside this backward (engine.TrainEngine's
+    # merged iteration: the discriminator step on a side stream) may take them over: module._defer_wgrad = (list, mask) - the launches
+    # selected by the mask (1 conv3, 2 up-sampling convs, 4 the grouped trunk launch, 8 conv1) are appended as (event recorded on this
+    # stream once their operands exist, launch closure, tensors) instead of issued; same kernels, same arguments.
+    dlist, dmask = module.__dict__.get("_defer_wgrad") or (None, 0)
+
+    def leaf(bit, launch, *tensors):
+        if dlist is not None and (dmask & bit):
+            ev = torch.cuda.Event()
+            ev.record()
+            dlist.append((ev, launch, tensors))
+        else:
+            with ops.SideStream(*tensors):
+                launch()
 
     def rows(t):
         return t.numel() // t.shape[-1]
@@ -230,11 +244,12 @@ def backward(module, params, sv, dsr, need_dx=False):
     u, slope, sr_pre = sv["last"]
     g3 = ops.clamp_bwd(dsr.contiguous(), sr_pre, dbias=grads["conv3.bias"])
     fast9 = _fast9(module, p)
-    with ops.SideStream(u, g3, grads["conv3.weight"]):
+    def w_conv3(u=u, g3=g3, slope=slope):
         if fast9:
             ops.wgrad_c3(u, g3, grads["conv3.weight"], 0, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
         else:
             ops.conv_wgrad(u, g3, grads["conv3.weight"], 9, 1, in_slope=slope, in_act=ACT_SLOPE if slope is not None else 0)
+    leaf(1, w_conv3, u, g3, grads["conv3.weight"])
     if fast9:
         g = ops.conv9_c3_fwd(g3, p["conv3.weight"], 1, wp=w9["conv3.dgrad"])              # d PReLU(u)
     else:
@@ -247,9 +262,10 @@ def backward(module, params, sv, dsr, need_dx=False):
         # PReLU backward + inverse PixelShuffle + the partial sums of (conv bias, slope) gradients in ONE pass, one finalize
         du = ops.act_bwd(g, us, slope=sl, dbias=grads[pre + ".0.bias"], dslope=grads[pre + ".2.weight"],
                          unshuffle=True)                                             # [B,h,w,4C] pre-shuffle grad
-        with ops.SideStream(u_in, du, grads[pre + ".0.weight"]):
+        def w_up(u_in=u_in, du=du, pre=pre, slope_in=slope_in):
             ops.conv_wgrad(u_in, du, grads[pre + ".0.weight"], 3, 1, in_slope=slope_in,
                            in_act=ACT_SLOPE if slope_in is not None else 0)
+        leaf(2, w_up, u_in, du, grads[pre + ".0.weight"])
         g = ops.conv_fwd(du, wd[pre + ".0.weight"], C, 3, 1)[0]    # d (input of the up-conv)
     # ---- u = BN(conv2(h_last)) + PReLU(z1)
     y3, m3, r3, s3, t3 = sv["conv2"]
@@ -314,12 +330,18 @@ def backward(module, params, sv, dsr, need_dx=False):
     # ---- c1 = PReLU(z1): gradient = trunk path (dh) + global skip (dskip)
     z1 = sv["z1"]
     dz1 = ops.act_bwd(dh, z1, g2=dskip, slope=a1, dbias=grads["conv1.0.bias"], dslope=grads["conv1.1.weight"])
-    with ops.SideStream(dz1, sv["x3"], grads["conv1.0.weight"]):
+    def w_conv1(dz1=dz1, x3=sv["x3"]):
         if fast9:
-            ops.wgrad_c3(dz1, sv["x3"], grads["conv1.0.weight"], 1)
+            ops.wgrad_c3(dz1, x3, grads["conv1.0.weight"], 1)
         else:
-            ops.conv_wgrad(sv["x3"], dz1, grads["conv1.0.weight"], 9, 1)
-    wg.run()
+            ops.conv_wgrad(x3, dz1, grads["conv1.0.weight"], 9, 1)
+    leaf(8, w_conv1, dz1, sv["x3"], grads["conv1.0.weight"])
+    if dlist is not None and (dmask & 4) and wg.jobs:
+        ev = torch.cuda.Event()
+        ev.record()
+        dlist.append((ev, wg.run, tuple(t for j in wg.jobs for t in j[:3])))
+    else:
+        wg.run()
     ops.join_side()
     dx = None
     if need_dx:

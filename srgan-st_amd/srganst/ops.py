@@ -710,6 +710,33 @@ def flatten_bn_counters(module):
 OVERLAP = False     # measured (round 1, MI355X): with the band kernels the side stream costs 7 % of the step - kept as an option
 _SIDE = {}
 
+# What hipStreamEndCapture (ROCm 7.2) accepts, established with tools/capture_probe.py (each pattern in its own process, trivial
+# kernels): any number of streams forked from the capture's ORIGIN stream, forks of forks, events between sibling branches, RCCL
+# collectives (their stream forks from the issuing branch) - as long as every SECOND-level stream (one that entered the capture through
+# a stream other than the origin) is joined into the origin stream itself.  A dependency edge - wait_stream or wait_event alike -
+# from a second-level stream into a first-level one makes hipStreamEndCapture fault (segmentation fault inside the runtime, no error
+# code): that was the "third concurrent branch" crash of round 2 (the discriminator's two passes on two streams inside the side branch
+# of the merged iteration, and side-stream weight gradients there, both joined the side branch).  The engines record the origin
+# stream of an open capture here and every join of a helper stream goes through check_capture_join, which refuses that edge.
+CAPTURE_ORIGIN = None
+TOPOLOGY_ERROR = None       # message of the last refusal (the capture's own teardown may raise over the exception)
+
+
+class CaptureTopologyError(RuntimeError):
+    pass
+
+
+def check_capture_join(dst_stream):
+    """Call before dst_stream.wait_stream(child) / wait_event(event of a child stream) where `child` was forked from dst_stream: legal
+    in eager mode and when dst_stream is the origin of the open capture, refused otherwise (see CAPTURE_ORIGIN)."""
+    global TOPOLOGY_ERROR
+    if CAPTURE_ORIGIN is not None and torch.cuda.is_current_stream_capturing() and dst_stream != CAPTURE_ORIGIN:
+        TOPOLOGY_ERROR = (
+            "a stream forked from a side branch of an open hipGraph capture may only be joined into the capture's origin stream: "
+            "joining it into the side branch makes hipStreamEndCapture fault on ROCm 7.2 (ops.CAPTURE_ORIGIN, tools/capture_probe.py). "
+            "Run this schedule outside the merged iteration (KERNEL.OVERLAP_GD = False) or without the helper stream.")
+        raise CaptureTopologyError(TOPOLOGY_ERROR)
+
 
 class SideStream:
     """with SideStream(tensors...):  the body runs on the side stream after everything issued so far on the
@@ -745,6 +772,7 @@ def join_side():
         main = torch.cuda.current_stream()
         side = _SIDE.get(main.device)
         if side is not None:
+            check_capture_join(main)
             main.wait_stream(side)
 
 

@@ -381,3 +381,14 @@ def test_train_engine_schedules_are_bit_identical(interval):
     out = run(True, False, True, pack_early=False)
     for k in ref:
         assert torch.equal(ref[k], out[k]), ("late pack", k)
+
+
+def test_capture_refuses_second_level_join():
+    """What crashed hipStreamEndCapture in round 2 ("a third concurrent branch") is a dependency edge from a second-level stream into a
+    first-level one (tools/capture_probe.py); ops.check_capture_join refuses it with CaptureTopologyError.  In a child process."""
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capture_topology_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=600)
+    assert "REFUSED:" in r.stdout and "ALIVE" in r.stdout and r.returncode == 0, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
