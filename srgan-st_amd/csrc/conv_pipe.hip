@@ -47,6 +47,10 @@ struct PipeArgs {
   int B, H, W, Cin, Cout, Ho, Wo;
   int R;                    // B*Ho: rows of the tall output image
   int tiles_x, n_mt, nfc, total_tiles, ncb, ksplit, cb_per, units;
+#ifdef SST_PIPE_ABLATE
+  int dbg;                  // dev build only (tools/build_ablate.sh, tools/ablate_pipe.py): 1 no LDS staging writes, 2 no epilogue, 4 no patch loads,
+                            // 8 weight refills from one cache-resident address, 16 no MFMAs
+#endif
   int gB, grows;            // coefficient groups: images per group (0 = one group) and rows of the tall output image per group.  The
                             // per-channel arrays (in_scale / in_shift, epi_scale / epi_shift) are then [B / gB][channels]: every group
                             // of gB consecutive images carries the BatchNorm coefficients of its own pass (several discriminator
@@ -243,6 +247,9 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
   // tile.  VALU work is not hidden behind the MFMAs on this chip: per stage it was 25 instructions per quad.
   unsigned boffs[MS ? NU : 1];
   auto stage_load = [&](const Stage& s, bool same_tile) {
+#ifdef SST_PIPE_ABLATE
+    if (a.dbg & 4) return;
+#endif
     if (MS && same_tile) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -276,6 +283,9 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
     PIPE_GLOAD(ssh, coff, sh_base);
   };
   auto stage_store = [&]() {
+#ifdef SST_PIPE_ABLATE
+    if (a.dbg & 1) return;
+#endif
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int p = p0 + 16 * u;
@@ -369,8 +379,14 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
         constexpr int dummy_ = 0;
         (void)dummy_;
         const int ai = MODE ? S2D_CLS[i >> 1] : 0;     // compile-time after unrolling
+#ifdef SST_PIPE_ABLATE
+        if (!(a.dbg & 16))
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[ai], 0, 0, 0);
+#ifdef SST_PIPE_ABLATE
+        if (a.dbg & 8) { PIPE_GLOAD(ring[i % PIPE_RING], wlane, a.wp); } else      // one cache-resident address: the load count (vmcnt) stays
+#endif
         if (i + PIPE_RING < 18) PIPE_WCHUNK(ring[i % PIPE_RING], cur.w, i + PIPE_RING);
         else PIPE_WCHUNK(ring[i % PIPE_RING], nxt.w, i + PIPE_RING - 18);
         if (i == 0) stage_load(nxt, !unit_end);
@@ -378,6 +394,13 @@ __global__ __launch_bounds__(CONV_NT, (S == 1 && MODE == 0 ? 3 : 2)) void conv_p
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef SST_PIPE_ABLATE
+    if (unit_end && (a.dbg & 2)) {
+      if (acc[0][0] == 12345.f) a.y[0] = acc[0][0];
+      if (!more) return;
+      a_base = lane_base(n_oy0);
+    } else
+#endif
     if (unit_end) {
       // ---- the 4 waves' K-partials -> LDS (NPAIR accumulators per round); afterwards wave w owns channels 8w .. 8w+7 of the
       // tile for all 32 pixels
@@ -535,6 +558,9 @@ SST_API int sst_conv_pipe_fwd_grp(const float* x, const float* wp, float* y, con
   a.ksplit = pl.ksplit; a.cb_per = pl.ncb / pl.ksplit; a.units = a.total_tiles * pl.ksplit;
   a.gB = (grp_images > 0 && grp_images < B) ? grp_images : 0;
   a.grows = a.gB * a.Ho;
+#ifdef SST_PIPE_ABLATE
+  a.dbg = sst_env("SST_PIPE_DBG") ? atoi(sst_env("SST_PIPE_DBG")) : 0;
+#endif
   int wg_per_cu = stride == 1 ? 3 : 2;                 // = the kernels' launch bounds (register-limited)
   if (const char* e = sst_env("SST_PIPE_GPC")) {        // dev: fewer resident workgroups leave room for kernels of other streams
     const int v = atoi(e);
@@ -633,6 +659,9 @@ SST_API int sst_conv_s2_dgrad_pipe_bwdstats(const float* dy, const float* wp, fl
   a.Ho = a.H; a.Wo = a.W; a.R = B * a.Ho;
   a.tiles_x = pl.tiles_x; a.n_mt = pl.n_mt; a.nfc = pl.nfc; a.total_tiles = pl.n_mt * pl.nfc; a.ncb = pl.ncb;
   a.ksplit = pl.ksplit; a.cb_per = pl.ncb / pl.ksplit; a.units = a.total_tiles * pl.ksplit;
+#ifdef SST_PIPE_ABLATE
+  a.dbg = 0;
+#endif
   a.gB = a.grows = 0;                      // the data-gradient's optional epilogue partials take one coefficient row
   const int grid = a.units < 2 * PIPE_CUS ? a.units : 2 * PIPE_CUS;
   hipStream_t st = sst_stream(stream);

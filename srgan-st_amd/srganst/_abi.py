@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsrganst.so")
+LIB_PATH = os.environ.get("SST_LIB_PATH") or os.path.join(_HERE, "lib", "libsrganst.so")      # SST_LIB_PATH: dev builds (ablation) of the library
 
 P = c_void_p  # device pointer
 
