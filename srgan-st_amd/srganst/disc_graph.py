@@ -69,7 +69,45 @@ def groups_supported(module, p, gB, groups, H, W):
     return B <= 64            # classifier kernels: at most 64 batch rows
 
 
-def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook=None, update_running=True):
+class PassArena:
+    """Activations of several passes side by side: every tensor the backward reads is allocated once for `slots` passes of B images
+    and each pass's forward (slot = its place) writes its slice.  Passes that ran separately - the generator step's D(sr) and, later,
+    the discriminator step's D(gt) (engine.TrainEngine with KERNEL.REUSE_D_SR) - can then be differentiated as ONE batch
+    (batched_saved): per-pass BatchNorm rows, one launch per layer over slots * B images."""
+
+    def __init__(self, slots):
+        self.slots, self.t, self.filled, self.meta = slots, {}, set(), None
+
+    def get(self, key, shape, like, slot, B):
+        t = self.t.get(key)
+        if t is None:
+            t = self.t[key] = torch.empty(self.slots * shape[0], *shape[1:], device=like.device, dtype=torch.float32)
+        return t[slot * B:(slot + 1) * B] if B else t[slot]
+
+
+def batched_saved(arena, sv_any):
+    """The saved-tensor record of `arena.slots` passes as one batch (what forward() on a list of inputs would have saved), once every slot
+    has been filled by a forward(..., arena=(arena, slot)) of the same weights."""
+    assert len(arena.filled) == arena.slots, "not every pass of the arena has run"
+    B = arena.meta["B"]
+    sv = {"layers": [], "groups": arena.slots, "gB": B, "wd": sv_any["wd"], "ws2": sv_any["ws2"],
+          "flat": arena.t["flat"], "h1": arena.t["h1"]}
+    h, scale, shift, act = arena.t["x3"], None, None, 0
+    for li, r in enumerate(sv_any["layers"]):
+        rec = {"x": h, "x_scale": scale, "x_shift": shift, "x_act": act, "y": arena.t[("y", li)], "ci": r["ci"], "bi": r["bi"],
+               "stride": r["stride"]}
+        if r["bi"] is not None:
+            rec["mean"], rec["rstd"] = arena.t[("mean", li)], arena.t[("rstd", li)]
+            scale, shift = arena.t[("scale", li)], arena.t[("shift", li)]
+        else:
+            scale = shift = None
+        rec["scale"], rec["shift"] = scale, shift
+        sv["layers"].append(rec)
+        h, act = rec["y"], ACT_SLOPE
+    return sv
+
+
+def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook=None, update_running=True, arena=None):
     """x: one NCHW batch, or a LIST of `groups` equally-shaped NCHW batches = that many passes of the discriminator run as ONE
     batch (each pass keeps its own train-mode BatchNorm statistics: per-pass scale / shift rows, running statistics updated pass by
     pass in list order, batch counters + groups) - the discriminator step's D(gt) and D(sr.detach()) (train.py:155-158) as one tall
@@ -83,6 +121,16 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
     if not update_running:
         bump_counters = False
     groups, gB = 1, 0
+    ar, slot = arena if arena is not None else (None, 0)      # (PassArena, slot): this pass writes its slice of the shared tensors
+    if ar is not None:
+        assert training and not isinstance(x, (list, tuple))
+        Bx = x.shape[0]
+        if ar.meta is None:
+            ar.meta = {"B": Bx}
+        assert ar.meta["B"] == Bx
+
+    def A(key, shape, like):
+        return ar.get(key, shape, like, slot, shape[0]) if ar is not None else None
     if isinstance(x, (list, tuple)):
         groups, gB = len(x), x[0].shape[0]
         if groups == 1:
@@ -100,14 +148,17 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
             assert xi.shape == x[0].shape
             ops.transpose(xi.contiguous(), to_nchw=False, out=x3[gi * gB:(gi + 1) * gB])
     else:
-        x3 = ops.transpose(x.contiguous(), to_nchw=False)
+        Bq, c3, hh, ww = x.shape
+        x3 = ops.transpose(x.contiguous(), to_nchw=False, out=A("x3", (Bq, hh, ww, c3), x))
     h, scale, shift, act = x3, None, None, 0
     for ci, bi, stride in PLAN:
         w = p[f"features.{ci}.weight"]
         cout = w.shape[0]
         bias = p.get(f"features.{ci}.bias")
+        ho, wo = ops.conv_out_hw(h.shape[1], h.shape[2], 3, stride)
         y, _, st, cnt = ops.conv_fwd(h, wp[f"features.{ci}.weight"], cout, 3, stride, bias=bias, in_scale=scale, in_shift=shift,
-                                     in_slope_const=LRELU, in_act=act, want_stats=(bi is not None and training), grp=gB)
+                                     in_slope_const=LRELU, in_act=act, want_stats=(bi is not None and training), grp=gB,
+                                     out=A(("y", len(sv["layers"])), (h.shape[0], ho, wo, cout), h))
         rec = {"x": h, "x_scale": scale, "x_shift": shift, "x_act": act, "y": y, "ci": ci, "bi": bi, "stride": stride}
         if bi is not None:
             bn = module.features[bi]
@@ -115,8 +166,12 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
             if training:
                 if bn_hook is not None:
                     bn_hook(len(sv["layers"]), "pre")
+                rows = None
+                if ar is not None:      # this pass's row of the [passes, C] coefficient tables
+                    li_ = len(sv["layers"])
+                    rows = tuple(ar.get((k, li_), (1, cout), h, slot, 0) for k in ("mean", "rstd", "scale", "shift"))
                 mean, rstd, scale, shift = ops.bn_finalize(st, cnt, g, b, bn.running_mean if update_running else None,
-                                                           bn.running_var if update_running else None, groups=groups)
+                                                           bn.running_var if update_running else None, groups=groups, out=rows)
                 if bn_hook is not None:
                     bn_hook(len(sv["layers"]), "post")
                 rec["mean"], rec["rstd"] = mean, rstd
@@ -128,8 +183,12 @@ def forward(module, x, p, training, need_grad=False, bump_counters=True, bn_hook
         rec["scale"], rec["shift"] = scale, shift
         sv["layers"].append(rec)
         h, act = y, ACT_SLOPE
-    flat = ops.flatten_act(h, scale, shift, LRELU, 1, grp=gB)               # [B, C*H*W]  (C,H,W) order
-    h1 = ops.linear_fwd(flat, p["classifier.0.weight"], p["classifier.0.bias"])   # pre-activation
+    nfeat = h.shape[1] * h.shape[2] * h.shape[3]
+    flat = ops.flatten_act(h, scale, shift, LRELU, 1, grp=gB, out=A("flat", (h.shape[0], nfeat), h))      # [B, C*H*W]  (C,H,W) order
+    h1 = ops.linear_fwd(flat, p["classifier.0.weight"], p["classifier.0.bias"],
+                        out=A("h1", (h.shape[0], p["classifier.0.weight"].shape[0]), h))   # pre-activation
+    if ar is not None:
+        ar.filled.add(slot)
     out = ops.head_fwd(h1, p["classifier.2.weight"], p["classifier.2.bias"], LRELU)
     sv["flat"], sv["h1"] = flat, h1
     return out, sv
@@ -296,10 +355,14 @@ class DiscriminatorFn(torch.autograd.Function):
         need_grad = need_param or need_dx
         if need_grad and not module.training:
             raise NotImplementedError("Discriminator backward in eval() mode is not on the reference's path (train.py:110)")
-        out, sv = forward(module, x, p, module.training, need_grad)
-        if module.__dict__.get("_keep_pass") and need_grad and module.training:
+        keep = module.__dict__.get("_keep_pass") and need_grad and module.training
+        req = module.__dict__.get("_arena_request") if keep else None          # (slots, slot): write this pass into a fresh PassArena
+        arena = (PassArena(req[0]), req[1]) if req is not None else None
+        out, sv = forward(module, x, p, module.training, need_grad, arena=arena)
+        if keep:
             # the step engine re-uses this pass (replay_running_stats): input identity, logits, saved activations
-            module.__dict__["_last_pass"] = {"x_ptr": x.data_ptr(), "x_shape": tuple(x.shape), "out": out, "sv": sv, "p": p}
+            module.__dict__["_last_pass"] = {"x_ptr": x.data_ptr(), "x_shape": tuple(x.shape), "out": out, "sv": sv, "p": p,
+                                             "arena": arena[0] if arena is not None else None}
         if need_grad:
             ctx.module, ctx.sv, ctx.p, ctx.names = module, sv, p, names
             ctx.need_param, ctx.need_dx = need_param, need_dx

@@ -368,6 +368,7 @@ class TrainEngine:
         self.g_opt.zero_grad(set_to_none=True)
         self.D.__dict__["_packs_fresh"] = False
         self.D.__dict__["_keep_pass"], self.D.__dict__["_last_pass"] = True, None      # _d_fwd_cls re-uses the D(sr) pass
+        self._request_arena()
         early_pack = cfg.KERNEL.EARLY_D_PACK and "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS
         if early_pack:                             # D's weight packing beside the generator's forward (as in _iter_gd)
             from . import disc_graph
@@ -385,6 +386,7 @@ class TrainEngine:
                                        adversarial=lambda crit: crit(self.D(sr), self.real),
                                        adv_logits=lambda: self.D(sr), adv_label=self.real)
         self.D.__dict__["_keep_pass"] = False
+        self.D.__dict__.pop("_arena_request", None)
         self.sr = sr.detach()
         self.loss_values = vals
         self._g_total = total
@@ -406,6 +408,22 @@ class TrainEngine:
             self._g_allreduce()
         self.g_opt.step()
         return v
+
+    def _request_arena(self):
+        """KERNEL.REUSE_D_SR + KERNEL.BATCH_D_STEP: the generator step's D(sr) pass writes its activations into slot 1 of a two-pass arena
+        (disc_graph.PassArena); the discriminator step's D(gt) fills slot 0 and ONE backward runs over both (_d_fwd_cls)."""
+        cfg = self.config
+        ok = (cfg.KERNEL.REUSE_D_SR and cfg.KERNEL.BATCH_D_STEP and "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS
+              and self.batch_num % cfg.SOLVER.D_UPDATE_INTERVAL == 0 and self.gt is not None)
+        if ok:
+            from . import disc_graph
+            names = [n for n, _ in self.D.named_parameters()]
+            pd = dict(zip(names, [t.detach() for t in self.D.parameters()]))
+            ok = disc_graph.groups_supported(self.D, pd, self.gt.shape[0], 2, self.gt.shape[2], self.gt.shape[3])
+        if ok:
+            self.D.__dict__["_arena_request"] = (2, 1)
+        else:
+            self.D.__dict__.pop("_arena_request", None)
 
     # -- discriminator half: train.py:149-164
     def _d_fwd_bwd(self):
@@ -470,6 +488,33 @@ class TrainEngine:
                 loss_real, _ = ops.bce_logits(pred_gt, self.real, want_loss=True, want_grad=True, grad_out=dl[:B])
                 loss_fake, _ = ops.bce_logits(pred_sr, self.fake, want_loss=True, want_grad=True, grad_out=dl[B:])
                 self.d_loss, self.pred_gt, self.pred_sr = loss_real + loss_fake, pred_gt, pred_sr
+                st = disc_graph.backward_classifier(D, pd, sv, dl, True)
+                self._d_state = (pd, None, None, sv, st)
+                self.d_batched = True
+                flat = D.__dict__["_flat_grads"][-1]
+                plist = [pd[n] for n in names]
+                offs, total = ops.flat_layout(plist)
+                cut = offs[names.index("classifier.0.weight")]
+                self._d_flat, self._d_buckets = flat, (flat[cut:total], flat[:cut])
+                return self.d_loss
+        if early_gt is None and kept is not None and kept.get("arena") is not None and self.config.KERNEL.BATCH_D_STEP:
+            pd = dict(zip(names, [t.detach() for t in D.parameters()]))
+            if (kept["x_ptr"] == self.sr.data_ptr() and kept["x_shape"] == tuple(self.sr.shape) and tuple(self.gt.shape) == tuple(self.sr.shape)
+                    and all(kept["p"][n].data_ptr() == pd[n].data_ptr() and kept["p"][n]._version == pd[n]._version for n in names)):
+                # The kept D(sr) pass sits in slot 1 of a two-pass arena: D(gt) fills slot 0, the running statistics take D(sr.detach())'s
+                # step (replayed, as below), and ONE backward runs over the 2B images with per-pass BatchNorm rows.
+                D.__dict__.pop("_last_pass", None)
+                B = self.gt.shape[0]
+                arena = kept["arena"]
+                pred_gt, sv_gt = disc_graph.forward(D, self.gt, pd, True, True, arena=(arena, 0))
+                disc_graph.replay_running_stats(D, pd, kept["sv"])
+                pred_sr = kept["out"].detach()
+                self.d_sr_reused = True
+                dl = torch.empty(2 * B, 1, device=pred_gt.device, dtype=torch.float32)
+                loss_real, _ = ops.bce_logits(pred_gt, self.real, want_loss=True, want_grad=True, grad_out=dl[:B])
+                loss_fake, _ = ops.bce_logits(pred_sr, self.fake, want_loss=True, want_grad=True, grad_out=dl[B:])
+                self.d_loss, self.pred_gt, self.pred_sr = loss_real + loss_fake, pred_gt, pred_sr
+                sv = disc_graph.batched_saved(arena, sv_gt)
                 st = disc_graph.backward_classifier(D, pd, sv, dl, True)
                 self._d_state = (pd, None, None, sv, st)
                 self.d_batched = True
@@ -602,6 +647,7 @@ class TrainEngine:
         self.g_opt.zero_grad(set_to_none=True)
         self.D.__dict__["_packs_fresh"] = False
         self.D.__dict__["_keep_pass"], self.D.__dict__["_last_pass"] = True, None
+        self._request_arena()
         from . import disc_graph, ops
         adv_d = "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS
         # the batch counters of D's BatchNorms move by one per pass (run or replayed): ONE add per iteration instead of three
@@ -630,6 +676,7 @@ class TrainEngine:
                                        adversarial=lambda crit: crit(self.D(sr), self.real),
                                        adv_logits=lambda: self.D(sr), adv_label=self.real)
         self.D.__dict__["_keep_pass"] = False
+        self.D.__dict__.pop("_arena_request", None)
         self.sr = sr.detach()
         ops.debug_stamp(2)
         self._side_d.wait_stream(main)

@@ -307,13 +307,17 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
     return dw_out
 
 
-def bn_finalize(stats, cnt, gamma, beta, run_mean=None, run_var=None, eps=BN_EPS, momentum=BN_MOMENTUM, groups=1):
+def bn_finalize(stats, cnt, gamma, beta, run_mean=None, run_var=None, eps=BN_EPS, momentum=BN_MOMENTUM, groups=1, out=None):
     """-> (mean, rstd, scale, shift); updates run_mean/run_var in place when given (train mode).
     groups > 1: the tiles are `groups` equal consecutive ranges (passes batched as one tall image): outputs [groups, C], one momentum
     step of the running statistics per group, in order."""
     C = gamma.numel()
     shape = (C,) if groups == 1 else (groups, C)
-    mean, rstd, scale, shift = (_f32(*shape, like=gamma) for _ in range(4))
+    if out is not None:          # (mean, rstd, scale, shift) rows to fill: one pass's row of a [passes, C] table (disc_graph's pass arena)
+        mean, rstd, scale, shift = out
+        assert all(tuple(t.shape) == shape and t.is_contiguous() for t in out)
+    else:
+        mean, rstd, scale, shift = (_f32(*shape, like=gamma) for _ in range(4))
     check(_abi.lib().sst_bn_finalize_grp(ptr(stats), ptr(cnt), stats.shape[0], C, int(groups), ptr(gamma), ptr(beta), ptr(run_mean),
                                          ptr(run_var), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), eps, momentum,
                                          stream_ptr()), "sst_bn_finalize")
@@ -551,10 +555,11 @@ def conv_s2_dgrad_fused(g, y2, wp, H, W, cin, cA=None, cB=None, cC=None, in_scal
     return dx, dy, partial
 
 
-def linear_fwd(x, w, bias):
+def linear_fwd(x, w, bias, out=None):
     M, K = x.shape
     N = w.shape[0]
-    y = _f32(M, N, like=x)
+    y = out if out is not None else _f32(M, N, like=x)
+    assert tuple(y.shape) == (M, N) and y.is_contiguous()
     slab = _f32(_abi.lib().sst_linear_ksplit(M, N, K) * M * N, like=x)
     args = (ptr(x), ptr(w), ptr(bias), ptr(y), ptr(slab), M, N, K)
     check(_abi.lib().sst_linear_fwd(*args, stream_ptr()), "sst_linear_fwd")
@@ -600,10 +605,11 @@ def head_bwd(h, w, dy, slope, dw=None, db=None, accumulate=False):
     return dh
 
 
-def flatten_act(y, scale, shift, slope, act=1, grp=0):
+def flatten_act(y, scale, shift, slope, act=1, grp=0, out=None):
     """NHWC [B,H,W,C] -> [B, C*H*W] in NCHW-flatten order with act(y*scale+shift) applied (grp > 0: scale / shift [B / grp, C])."""
     B, H, W, C = y.shape
-    flat = _f32(B, C * H * W, like=y)
+    flat = out if out is not None else _f32(B, C * H * W, like=y)
+    assert tuple(flat.shape) == (B, C * H * W) and flat.is_contiguous()
     check(_abi.lib().sst_flatten_act_grp(ptr(y), ptr(scale), ptr(shift), float(slope), int(act), ptr(flat), B, H * W, C, int(grp),
                                          stream_ptr()), "sst_flatten_act")
     return flat

@@ -171,9 +171,12 @@ def test_discriminator_two_passes_as_one_batch():
     assert worst[0] < 2e-4, worst
 
 
-def test_train_iteration_batched_d_step_matches_sequential():
-    """The whole iteration (engine.TrainEngine, merged schedule, three discriminator forwards) with the discriminator step's two passes
-    as one batch (KERNEL.BATCH_D_STEP) against the same schedule pass by pass.  The discriminator's gradients are ill-conditioned in
+@pytest.mark.parametrize("reuse", [False, True])
+def test_train_iteration_batched_d_step_matches_sequential(reuse):
+    """The whole iteration (engine.TrainEngine, merged schedule) with the discriminator step's two passes as one batch
+    (KERNEL.BATCH_D_STEP) against the same schedule pass by pass - reuse False: three discriminator forwards, D(gt) and D(sr.detach())
+    run as one tall image; reuse True (KERNEL.REUSE_D_SR, the engine's default): the generator step's D(sr) pass is kept in slot 1 of
+    a two-pass arena, D(gt) fills slot 0, ONE backward over both.  The discriminator's gradients are ill-conditioned in
     fp32 (BatchNorm backward subtracts nearly all of its input: two fp32 evaluations in different summation orders differ by ~1e-3,
     as the reference's own fp32 run does from fp64 - DESIGN.md section 2), so the yardstick is the fp64 truth: the batched step's
     distance from oracle/ run in fp64 on the same sr / gt must be within max(1e-3, 3 x the pass-by-pass schedule's own distance).
@@ -190,7 +193,7 @@ def test_train_iteration_batched_d_step_matches_sequential():
     def run(batched, use_graph, steps):
         cfg = Config()
         cfg.MODEL.G_N_RCB = 2
-        cfg.KERNEL.REUSE_D_SR, cfg.KERNEL.BATCH_D_STEP = False, batched
+        cfg.KERNEL.REUSE_D_SR, cfg.KERNEL.BATCH_D_STEP = reuse, batched
         torch.manual_seed(1)
         D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
         d0 = {k: v.detach().clone().cpu() for k, v in D.state_dict().items()}
@@ -203,7 +206,7 @@ def test_train_iteration_batched_d_step_matches_sequential():
             gt = torch.rand(8, 3, 96, 96, generator=gen)
             eng.step(gt.cuda(), torch.rand(8, 3, 24, 24, generator=gen).cuda())
         torch.cuda.synchronize()
-        assert eng.graph_active == use_graph and eng.d_batched == batched
+        assert eng.graph_active == use_graph and eng.d_batched == batched and eng.d_sr_reused == reuse
         sd = {"G." + k: v.clone() for k, v in G.state_dict().items()}
         sd.update({"D." + k: v.clone() for k, v in D.state_dict().items()})
         sd["d_loss"], sd["pred_gt"], sd["pred_sr"] = eng.d_loss.clone(), eng.pred_gt.clone(), eng.pred_sr.clone()
@@ -216,7 +219,7 @@ def test_train_iteration_batched_d_step_matches_sequential():
     outg, _, _, _, _ = run(True, True, 4)
     for k in out4:
         assert torch.equal(out4[k], outg[k]), ("graph replay differs from eager", k)
-    assert int(out4["D.features.3.num_batches_tracked"]) == 12
+    assert int(out4["D.features.3.num_batches_tracked"]) == 12        # three passes per iteration, run or replayed
 
     ref, g_seq, sr_seq, gt, d0 = run(False, False, 1)
     out, g_bat, sr_bat, _, _ = run(True, False, 1)

@@ -67,10 +67,11 @@ _BENCH_ORACLE = {}
 
 @pytest.mark.parametrize("schedule", ["shared", "batched"])
 def test_train_iteration_bench_size_vs_oracle(schedule):
-    """schedule "shared": the engine's default (the discriminator step works on the generator step's D(sr) pass, KERNEL.REUSE_D_SR);
-    "batched": the bench headline's schedule - all three discriminator forwards, the discriminator step's two passes as ONE batch of
-    2B images with per-pass BatchNorm statistics (KERNEL.BATCH_D_STEP), whose weight gradients sum over 32 images in one kernel: its
-    parity statement IS this fp64-truth rule (no bit-identity with the pass-by-pass schedule is claimed).
+    """schedule "shared": the engine's default (the discriminator step works on the generator step's D(sr) pass, KERNEL.REUSE_D_SR: kept
+    in a two-pass arena, D(gt) joins it, one backward over both); "batched": the bench headline's schedule - all three discriminator
+    forwards, the discriminator step's two passes as ONE batch of 2B images with per-pass BatchNorm statistics (KERNEL.BATCH_D_STEP).
+    In both the weight gradients sum over 32 images in one kernel: the parity statement IS this fp64-truth rule (no bit-identity with
+    the pass-by-pass schedule is claimed).
 
     The bench line's own workload on the bench line's own code path: full-size generator (16 residual blocks) and discriminator,
     B = 16, 96-px crops, the default engine schedule (whole iteration as one launch DAG, discriminator step on a side stream;
@@ -139,7 +140,7 @@ def test_train_iteration_bench_size_vs_oracle(schedule):
     cfg.SOLVER.D_UPDATE_INTERVAL = 1
     eng = TrainEngine(cfg, G, D, use_graph=False)
     losses, d_loss = eng.step(gt.cuda(), lr.cuda())
-    assert eng.d_batched == (schedule == "batched") and eng.d_sr_reused == (schedule == "shared")
+    assert eng.d_batched and eng.d_sr_reused == (schedule == "shared")      # one backward over 2B images in both schedules
     assert rel_err(eng.sr.cpu(), sr32) < 1e-3
     print(f"clamp flips against fp64 on seed {chosen}: hip {_clamp_flips(eng.sr.cpu(), sr64)}, oracle fp32 {_clamp_flips(sr32, sr64)}, "
           f"oracle on the GPU {_clamp_flips(srm, sr64)}")
