@@ -454,6 +454,7 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_kernel(const float* __rest
 // keep the VALU kernel above.
 constexpr int C3M_ROW = 104;                 // floats per patch row in LDS (34 px x 3 ch = 102, padded)
 constexpr int C3M_WAVE = 3 * C3M_ROW + 96;   // + the zero region the idle columns read (16 K steps x 6 floats)
+constexpr int C3M_TPW = 4;                   // row segments a wave accumulates before the workgroup writes its partial
 __global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                   float* __restrict__ slab, int B, int H, int W, int ntiles) {
   __shared__ float patch[4 * C3M_WAVE];
@@ -462,9 +463,22 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_mfma_kernel(const float* _
   const int li = lane & 31, lh = lane >> 5;
   constexpr int Cout = 64;
   float* const ps = patch + wave * C3M_WAVE;
-  const int t = blockIdx.x * 4 + wave;
-  const bool live = t < ntiles;
   const int tpr = W >> 5;                                 // tiles per image row
+  // this lane's column n = li = ky*9 + kx*3 + ci  ->  fixed offset into the patch (+ 3 floats for the pair's second pixel)
+  const int ky = li / 9, kr = li - ky * 9;
+  const float* const bl = ps + (li < 27 ? ky * C3M_ROW + kr + 3 * lh : 3 * C3M_ROW);
+  f32x16 acc[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+  for (int i = lane; i < 96; i += 64) ps[3 * C3M_ROW + i] = 0.f;      // the zero region the idle columns read
+  // a wave accumulates C3M_TPW row segments (tiles blockIdx.x * 4 * C3M_TPW + wave + 4 i) before the workgroup writes its partial:
+  // one 64 x 27 partial per 4 * C3M_TPW tiles - the slab and its reduce (15.9 MB / 43 us with one partial per 4 tiles at B = 32)
+  // shrink by C3M_TPW
+  for (int it = 0; it < C3M_TPW; ++it) {
+  const int t = (blockIdx.x * C3M_TPW + it) * 4 + wave;
+  const bool live = t < ntiles;
   const int b = t / (H * tpr), rem = t - b * (H * tpr);
   const int y = rem / tpr, x0 = (rem - y * tpr) << 5;
   // dY in MFMA layout: K step ks, half h -> channel 32h + li of pixel x0 + 2ks + lh
@@ -488,21 +502,13 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_mfma_kernel(const float* _
       ps[r * C3M_ROW + c] = ok ? x[((size_t)b * H + iy) * W * 3 + fx] : 0.f;
     }
   }
-  for (int i = lane; i < 96; i += 64) ps[3 * C3M_ROW + i] = 0.f;
-  // this lane's column n = li = ky*9 + kx*3 + ci  ->  fixed offset into the patch (+ 3 floats for the pair's second pixel)
-  const int ky = li / 9, kr = li - ky * 9;
-  const float* const bl = ps + (li < 27 ? ky * C3M_ROW + kr + 3 * lh : 3 * C3M_ROW);
-  f32x16 acc[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const float bv = bl[6 * ks];                          // LDS ops of a wave complete in order: the stores above have landed
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][0], bv, acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][1], bv, acc[1], 0, 0, 0);
   }
+  }   // tiles of this wave
   // 4 waves -> one 64 x 27 partial (fixed order), slab [chunk][tap][Cout][3]
   float* const out = slab + (size_t)blockIdx.x * 9 * Cout * 3;
 #pragma unroll
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(1024) void c3m_reduce_kernel(const float* __restric
   }
 }
 inline bool k3c3_mfma_applies(int W, int Cout) { return (W & 31) == 0 && Cout == 64 && !sst_env("SST_WGRAD_NO_K3C3_MFMA"); }
-inline int k3c3_mfma_chunks(int B, int H, int W) { return (B * H * (W >> 5) + 3) / 4; }
+inline int k3c3_mfma_chunks(int B, int H, int W) { return (B * H * (W >> 5) + 4 * C3M_TPW - 1) / (4 * C3M_TPW); }
 
 inline bool k3c3_applies(int Cin, int ksize, int stride, const float* in_scale, int in_act) {
   return Cin == 3 && ksize == 3 && stride == 1 && !in_scale && in_act == ACT_NONE;

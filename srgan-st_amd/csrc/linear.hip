@@ -84,6 +84,9 @@ __global__ __launch_bounds__(NT) void linear_reduce_kernel(const float* __restri
 
 // ---- dgrad: grid (K/64); wave w handles n in [w*N/4, (w+1)*N/4), 4 rows of W per step, 64 k-columns per workgroup.
 // Lane (lj, lq) loads float4 W[n+lq][k0 + 4 lj ..]: MFMA t (t = 0..3) uses element t => column k0 + 4 lj + t.
+// MT = 16-row tiles of the batch (M <= 16 MT): W is streamed ONCE for all of them (a 32-row batch - the discriminator step's two
+// passes as one - went over the 75.5 MB weight twice in the first form of this kernel).
+template <int MT>
 __global__ __launch_bounds__(NT) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                           float* __restrict__ dx, int M, int N, int K, int C, int HW) {
   __shared__ float red[4][16][65];
@@ -92,59 +95,69 @@ __global__ __launch_bounds__(NT) void linear_dgrad_kernel(const float* __restric
   const int k0 = blockIdx.x * 64;
   const int nper = ((N + 3) / 4 + 3) / 4 * 4;
   const int nb = wave * nper, ne = min(N, nb + nper);
-  const int mt = (M + 15) / 16;
-  for (int t0 = 0; t0 < mt; ++t0) {          // one 16-row batch tile at a time (M <= 16 in the hot path)
-    f32x4 acc[4];
+  f32x4 acc[MT][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int m = t0 * 16 + lj;
-    int n = nb;
-    if (k0 + 64 <= K) {
-      // main part: 8 steps (32 rows of W) per iteration with all 8 16-B loads issued before the first MFMA - the op streams
-      // W once (75 MB for the 1024 x 18432 classifier) and a wave with ONE load in flight ran it at 1.7 TB/s
-      constexpr int U = 8;
-      const float* wcol = w + k0 + 4 * lj;
-      for (; n + 4 * U <= ne; n += 4 * U) {
-        f32x4 bv[U];
-        float av[U];
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int nn = n + 4 * u + lq;
-          bv[u] = *reinterpret_cast<const f32x4*>(wcol + (size_t)nn * K);
-          av[u] = m < M ? dy[(size_t)m * N + nn] : 0.f;
+    for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int n = nb;
+  if (k0 + 64 <= K) {
+    // main part: U steps (4 U rows of W) per iteration with all 16-B loads issued before the first MFMA - the op streams
+    // W once (75 MB for the 1024 x 18432 classifier) and a wave with ONE load in flight ran it at 1.7 TB/s
+    constexpr int U = MT == 1 ? 8 : 4;
+    const float* wcol = w + k0 + 4 * lj;
+    for (; n + 4 * U <= ne; n += 4 * U) {
+      f32x4 bv[U];
+      float av[MT][U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int nn = n + 4 * u + lq;
+        bv[u] = *reinterpret_cast<const f32x4*>(wcol + (size_t)nn * K);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m = mt * 16 + lj;
+          av[mt][u] = m < M ? dy[(size_t)m * N + nn] : 0.f;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][t], acc[t], 0, 0, 0);
-      }
-    }
-    for (; n < ne; n += 4) {
-      const int nn = n + lq;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      float av = 0.f;
-      if (nn < ne) {
-        const int kk = k0 + 4 * lj;
-        if (kk + 3 < K) {
-          bv = *reinterpret_cast<const f32x4*>(w + (size_t)nn * K + kk);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (kk + j < K) bv[j] = w[(size_t)nn * K + kk + j];
-        }
-        if (m < M) av = dy[(size_t)m * N + nn];
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][u], bv[u][t], acc[mt][t], 0, 0, 0);
     }
+  }
+  for (; n < ne; n += 4) {
+    const int nn = n + lq;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (nn < ne) {
+      const int kk = k0 + 4 * lj;
+      if (kk + 3 < K) {
+        bv = *reinterpret_cast<const f32x4*>(w + (size_t)nn * K + kk);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (kk + j < K) bv[j] = w[(size_t)nn * K + kk + j];
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + lj;
+      const float av = (nn < ne && m < M) ? dy[(size_t)m * N + nn] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[mt][t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][4 * lq + r][4 * lj + t] = acc[t][r];
+      for (int r = 0; r < 4; ++r) red[wave][4 * lq + r][4 * lj + t] = acc[mt][t][r];
     __syncthreads();
     for (int i = threadIdx.x; i < 16 * 64; i += NT) {
-      const int mm = i >> 6, kc = i & 63, mg = t0 * 16 + mm, k = k0 + kc;
+      const int mm = i >> 6, kc = i & 63, mg = mt * 16 + mm, k = k0 + kc;
       if (mg < M && k < K) {
         const float v = red[0][mm][kc] + red[1][mm][kc] + red[2][mm][kc] + red[3][mm][kc];
         // k indexes the NCHW flatten (c, hw); HW > 0 scatters to NHWC [M][HW][C]
@@ -194,6 +207,55 @@ __global__ __launch_bounds__(NT) void linear_wgrad_kernel(const float* __restric
     } else {
       for (int q = 0; q < 4; ++q)
         if (k + q < K) d[q] = accumulate ? d[q] + acc[j][q] : acc[j][q];
+    }
+  }
+}
+
+// ---- wgrad on the matrix cores (K % 32 == 0, N % 64 == 0): dw = dy^T x as a GEMM with the batch as its (short) K dimension.  A wave owns
+// a 64 (n) x 32 (k) block of dw: per pair of batch rows one dword of x per lane (128-B row segments) feeds two
+// v_mfma_f32_32x32x2_f32, the block leaves as 128-B row segments of dw - the kernel streams dw once (write-bound); the FMA form above
+// spends 16 LDS reads per 64 FMAs per batch row and took 41 us at 32 rows (28 at 16).  Sum order over m: the MFMA's (pairs in order).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(NT) void linear_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               float* __restrict__ dw, int M, int N, int K, int accumulate) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int k0 = (blockIdx.x * 4 + wave) * 32, n0 = blockIdx.y * 64;
+  if (k0 >= K) return;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  const float* xp = x + (size_t)lh * K + k0 + li;          // x[2j + lh][k0 + li]
+  const float* dp = dy + (size_t)lh * N + n0 + li;         // dy[2j + lh][n0 + li] (and + 32)
+  const int steps = (M + 1) >> 1;
+  for (int j0 = 0; j0 < steps; j0 += 8) {                  // 8 row pairs per batch: the loads of a batch are issued before its MFMAs
+    float xv[8], d0[8], d1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int m = 2 * (j0 + u) + lh;
+      const bool ok = j0 + u < steps && m < M;
+      xv[u] = ok ? xp[(size_t)2 * (j0 + u) * K] : 0.f;
+      d0[u] = ok ? dp[(size_t)2 * (j0 + u) * N] : 0.f;
+      d1[u] = ok ? dp[(size_t)2 * (j0 + u) * N + 32] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[u], xv[u], acc0, 0, 0, 0);      // rows n0 .. n0+31
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[u], xv[u], acc1, 0, 0, 0);      // rows n0+32 .. n0+63
+    }
+  }
+  // acc[r]: row (r & 3) + 8 * (r >> 2) + 4 * lh of the 32-row block, column li
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    float* d = dw + (size_t)(n0 + row) * K + k0 + li;
+    float* e = d + (size_t)32 * K;
+    if (accumulate) {
+      *d += acc0[r];
+      *e += acc1[r];
+    } else {
+      *d = acc0[r];
+      *e = acc1[r];
     }
   }
 }
@@ -324,7 +386,14 @@ SST_API int sst_linear_dgrad(const float* dy, const float* w, float* dx, int M, 
                              void* stream) {
   SST_REQUIRE(dy && w && dx && M > 0 && M <= MAXM && N > 0 && K > 0, "sst_linear_dgrad: bad argument");
   SST_REQUIRE(nhwc_HW == 0 || nhwc_C * nhwc_HW == K, "sst_linear_dgrad: C*HW must equal K");
-  linear_dgrad_kernel<<<(K + 63) / 64, NT, 0, sst_stream(stream)>>>(dy, w, dx, M, N, K, nhwc_C, nhwc_HW);
+  const int grid = (K + 63) / 64;
+  hipStream_t st = sst_stream(stream);
+  switch ((M + 15) / 16) {
+    case 1: linear_dgrad_kernel<1><<<grid, NT, 0, st>>>(dy, w, dx, M, N, K, nhwc_C, nhwc_HW); break;
+    case 2: linear_dgrad_kernel<2><<<grid, NT, 0, st>>>(dy, w, dx, M, N, K, nhwc_C, nhwc_HW); break;
+    case 3: linear_dgrad_kernel<3><<<grid, NT, 0, st>>>(dy, w, dx, M, N, K, nhwc_C, nhwc_HW); break;
+    default: linear_dgrad_kernel<4><<<grid, NT, 0, st>>>(dy, w, dx, M, N, K, nhwc_C, nhwc_HW); break;
+  }
   SST_LAUNCH_CHECK("linear_dgrad_kernel");
   return SST_OK;
 }
@@ -332,9 +401,14 @@ SST_API int sst_linear_dgrad(const float* dy, const float* w, float* dx, int M, 
 SST_API int sst_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, int accumulate,
                              void* stream) {
   SST_REQUIRE(dy && x && dw && M > 0 && M <= MAXM && N > 0 && K > 0, "sst_linear_wgrad: bad argument");
-  dim3 grid((K + 4 * NT - 1) / (4 * NT), (N + 15) / 16);
-  linear_wgrad_kernel<<<grid, NT, 0, sst_stream(stream)>>>(dy, x, dw, M, N, K, accumulate);
-  SST_LAUNCH_CHECK("linear_wgrad_kernel");
+  if ((K & 31) == 0 && (N & 63) == 0 && !sst_env("SST_LINEAR_WGRAD_FMA")) {
+    linear_wgrad_mfma_kernel<<<dim3((K / 32 + 3) / 4, N / 64), NT, 0, sst_stream(stream)>>>(dy, x, dw, M, N, K, accumulate);
+    SST_LAUNCH_CHECK("linear_wgrad_mfma_kernel");
+  } else {
+    dim3 grid((K + 4 * NT - 1) / (4 * NT), (N + 15) / 16);
+    linear_wgrad_kernel<<<grid, NT, 0, sst_stream(stream)>>>(dy, x, dw, M, N, K, accumulate);
+    SST_LAUNCH_CHECK("linear_wgrad_kernel");
+  }
   if (db) {
     colsum_small_kernel<<<(N + 255) / 256, 256, 0, sst_stream(stream)>>>(dy, db, M, N, accumulate);
     SST_LAUNCH_CHECK("colsum_small_kernel");

@@ -143,6 +143,12 @@ class Config:
         # the discriminator branch's persistent conv kernels leave it), the moved launches just run after everything else.  Stream
         # priorities change nothing either (main high: 5.00 ms; side high: 8.55 ms)
         self.KERNEL.DEFER_G_WGRAD = int(os.environ.get("SST_DEFER_G_WGRAD", "0"))
+        # merged iteration: where the discriminator step's branch forks off the generator's stream - 0: after the generator step's forward
+        # and losses (round 2), 1: after the generator's backward has passed the discriminator's classifier, 2: after it has left the
+        # discriminator altogether.  The generator's backward is a chain of short launches that only advances when the other branch's
+        # persistent conv kernels let it (its first launches - a 1-workgroup BCE backward, the classifier's data-gradient - took 75 /
+        # 123 us beside the discriminator step's forward, 5 / 37 us alone): what runs before the fork runs at full speed
+        self.KERNEL.FORK_D_STEP_AT = int(os.environ.get("SST_FORK_D_STEP_AT", "0"))
         self.KERNEL.EARLY_D_PACK = os.environ.get("SST_EARLY_D_PACK", "1") != "0"
         self.KERNEL.REUSE_D_SR = os.environ.get("SST_REUSE_D_SR", "1") != "0"
         # the discriminator step's two passes, D(gt) and D(sr.detach()) (train.py:155-158), as ONE batch of 2B images with per-pass

@@ -342,7 +342,11 @@ def backward(module, p, sv, dout, need_param_grads, need_dx):
     hook = module.__dict__.get("_after_cls_bwd")
     if hook is not None:             # engine.TrainEngine: the classifier's weights have been read for the last time on this stream
         hook()
-    return backward_features(module, p, sv, st, need_param_grads, need_dx)
+    out = backward_features(module, p, sv, st, need_param_grads, need_dx)
+    hook = module.__dict__.get("_after_bwd")
+    if hook is not None:             # engine.TrainEngine: the generator's backward has left the discriminator
+        hook()
+    return out
 
 
 class DiscriminatorFn(torch.autograd.Function):

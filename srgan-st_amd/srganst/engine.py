@@ -679,23 +679,32 @@ class TrainEngine:
         self.D.__dict__.pop("_arena_request", None)
         self.sr = sr.detach()
         ops.debug_stamp(2)
-        self._side_d.wait_stream(main)
         side = self._side_d
-        with torch.cuda.stream(side):           # both passes on ONE side stream: a third concurrent branch (the two passes on two
-            ops.debug_stamp(3)
-            self._d_fwd_cls(early_gt)           # streams, as _d_two_stream does on its own) crashed hipStreamEndCapture (ROCm 7.2)
-            ops.debug_stamp(4)
-            # data parallel, one graph: the classifier bucket (75.5 MB) goes out now, under the feature stack's backward.  The
-            # collective runs on the process group's own stream - forked from this side stream, i.e. a second-level fork: its
-            # wait() below is issued on `main`, the capture's origin stream (a second-level stream joined into a first-level one
-            # is what crashes hipStreamEndCapture).
-            ar_c = sdist.AsyncAllReduce(self._d_buckets[0], self.pg, force=True) if self.one_graph_dp else None
+        dp_ar = {}
+
+        def start_side():                       # the discriminator step's branch forks HERE off the stream the caller runs on (main)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):       # both passes on ONE side stream (a helper stream forked from it could only be joined into
+                ops.debug_stamp(3)              # `main`: ops.check_capture_join)
+                self._d_fwd_cls(early_gt)
+                ops.debug_stamp(4)
+                # data parallel, one graph: the classifier bucket (75.5 MB) goes out now, under the feature stack's backward.  The
+                # collective runs on the process group's own stream - forked from this side stream, i.e. a second-level fork: its
+                # wait() below is issued on `main`, the capture's origin stream (a second-level stream joined into a first-level one
+                # is what crashes hipStreamEndCapture).
+                dp_ar["c"] = sdist.AsyncAllReduce(self._d_buckets[0], self.pg, force=True) if self.one_graph_dp else None
+        fork_at = int(cfg.KERNEL.FORK_D_STEP_AT) if adv_d else 0
+        if fork_at == 0:
+            start_side()
+        else:
+            self.D.__dict__["_after_cls_bwd" if fork_at == 1 else "_after_bwd"] = start_side
         # D's Adam in two parts (KERNEL.SPLIT_D_ADAM): the classifier's gradient is complete here; its weights are read once more,
         # by the head of the generator's backward (through D), which hands over with an event - then the classifier's update runs on
         # the side stream beside the rest of both branches and only the feature stack's (4.7 M parameters) is left for the join.
         names = [n for n, _ in self.D.named_parameters()]
         cls0 = names.index("classifier.0.weight")
-        split = bool(cfg.KERNEL.SPLIT_D_ADAM) and not self.dp and self._d_flat is not None and hasattr(self.d_opt, "step_params")
+        split = (bool(cfg.KERNEL.SPLIT_D_ADAM) and not self.dp and fork_at == 0 and self._d_flat is not None
+                 and hasattr(self.d_opt, "step_params"))
 
         def cls_adam():
             ev = torch.cuda.Event()
@@ -719,6 +728,7 @@ class TrainEngine:
                 total.backward(_one(total))
         finally:
             self.D.__dict__.pop("_after_cls_bwd", None)
+            self.D.__dict__.pop("_after_bwd", None)
             self.G.__dict__.pop("_defer_wgrad", None)
         ops.debug_stamp(7)
         self.loss_values = vals
@@ -756,7 +766,7 @@ class TrainEngine:
         if g_def:
             self.g_opt.step()                    # its last weight gradients came from the side stream
         if self.one_graph_dp:
-            ar_c.wait()                          # on the origin stream
+            dp_ar["c"].wait()                    # on the origin stream
             ar_f.wait()
         if split:
             self.d_opt.step_params(0, cls0, flat_grad=self._d_flat)

@@ -44,8 +44,9 @@ def test_conv_s2_dgrad(ops, case):
     assert rel_err(nchw(dx.cpu()), x.grad) < TOL
 
 
-@pytest.mark.parametrize("case", [(16, 1024, 18432), (4, 40, 576), (16, 1024, 1000), (33, 24, 100)])
+@pytest.mark.parametrize("case", [(16, 1024, 18432), (32, 1024, 18432), (4, 40, 576), (16, 1024, 1000), (33, 24, 100), (33, 64, 96), (1, 128, 64)])
 def test_linear_fwd_dgrad_wgrad(ops, case):
+    # (the weight gradient runs on the matrix cores when K % 32 == 0 and N % 64 == 0 - odd batch sizes included - else as FMAs)
     M, N, K = case
     g = torch.Generator().manual_seed(22)
     x = torch.randn(M, K, generator=g, dtype=torch.float64, requires_grad=True)
@@ -60,6 +61,8 @@ def test_linear_fwd_dgrad_wgrad(ops, case):
     dw, db = torch.empty_like(wd), torch.empty_like(bd)
     ops.linear_wgrad(dyd, xd, dw, db)
     assert rel_err(dw.cpu(), w.grad) < TOL and rel_err(db.cpu(), b.grad) < TOL
+    ops.linear_wgrad(dyd, xd, dw, db, accumulate=True)                  # the second pass of a two-pass step adds into the first one's
+    assert rel_err(dw.cpu(), 2 * w.grad) < TOL and rel_err(db.cpu(), 2 * b.grad) < TOL
 
 
 def test_linear_dgrad_nhwc_scatter_and_flatten(ops):
@@ -392,3 +395,39 @@ def test_capture_refuses_second_level_join():
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capture_topology_child.py")
     r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=600)
     assert "REFUSED:" in r.stdout and "ALIVE" in r.stdout and r.returncode == 0, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_train_engine_schedules_bit_identical_full_width_discriminator():
+    """The schedule test above at D_N_CHANNEL = 8 never dispatches the pipelined conv kernel, the MFMA first-layer kernels or the all-taps
+    weight-gradient kernel.  Here the discriminator has its full width (64 channels; B = 4: too small for the batched discriminator
+    step, so every schedule runs the passes one by one): sequential eager against the merged iteration under hipGraph replay, with
+    and without the shared D(sr) pass - parameters, buffers and losses bit for bit."""
+    from srganst.engine import TrainEngine
+    from srganst.loss import MSELoss, StructureTensorLoss
+    from srganst.model import Discriminator, Generator
+
+    def run(gd, use_graph, reuse):
+        cfg = make_cfg(16, 2, 64)
+        cfg.KERNEL.OVERLAP_GD, cfg.KERNEL.REUSE_D_SR = gd, reuse
+        torch.manual_seed(1)
+        D, G = Discriminator(cfg).cuda().train(), Generator(cfg).cuda().train()
+        cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
+        cfg.add_g_criterion("ST", StructureTensorLoss(), 1 / 3)
+        cfg.SOLVER.D_UPDATE_INTERVAL = 1
+        eng = TrainEngine(cfg, G, D, use_graph=use_graph, adam_capturable=True)
+        gen = torch.Generator().manual_seed(2)
+        for _ in range(4):
+            eng.step(torch.rand(4, 3, 96, 96, generator=gen).cuda(), torch.rand(4, 3, 24, 24, generator=gen).cuda())
+        torch.cuda.synchronize()
+        assert eng.graph_active == use_graph and not eng.d_batched
+        sd = {"G." + k: v.clone() for k, v in G.state_dict().items()}
+        sd.update({"D." + k: v.clone() for k, v in D.state_dict().items()})
+        sd.update({"loss." + k: v.clone() for k, v in eng.loss_values.items()})
+        sd["d_loss"] = eng.d_loss.clone()
+        eng.close()
+        return sd
+    ref = run(False, False, False)
+    for gd, use_graph, reuse in ((True, True, True), (True, True, False)):
+        out = run(gd, use_graph, reuse)
+        for k in ref:
+            assert torch.equal(ref[k], out[k]), (gd, use_graph, reuse, k)

@@ -88,7 +88,8 @@ def test_train_iteration_bench_size_vs_oracle(schedule):
         fails the CPU-only 3x rule on 6-40 of 153 parameters depending on the seed.  The yardstick per parameter is therefore the
         LARGER error of the two fp32 references (oracle on CPU, oracle on the GPU), both against fp64.
     Criterion: whole-network gradient (all parameters as one vector) within max(1e-3, 3 x yardstick) for G and for D; per parameter
-    the same bound for at least 95 % of the parameters and 10 x the bound for every one of them (a wrong kernel is off by O(1))."""
+    the same bound for at least 95 % of the parameters and 3 x the bound for every one of them (a wrong kernel is off by O(1);
+    measured in rounds 2 and 3: no parameter beyond the 1 x bound on either schedule)."""
     from oracle import model as om
     from oracle import steps as osteps
     from srganst.config import Config
@@ -161,7 +162,7 @@ def test_train_iteration_bench_size_vs_oracle(schedule):
         for n in names:
             e = rel_err(hip[n], r64[n])
             bound = max(TRUTH_FLOOR, TRUTH_FACTOR * max(rel_err(r32[n], r64[n]), rel_err(rgm[n], r64[n])))
-            assert e <= 10 * bound, f"{tag}.{n}: |hip - fp64| = {e:.3e} > 10 x max(1e-3, 3 x fp32 references) = {10 * bound:.3e}"
+            assert e <= 3 * bound, f"{tag}.{n}: |hip - fp64| = {e:.3e} > 3 x max(1e-3, 3 x fp32 references) = {3 * bound:.3e}"
             if e > bound:
                 beyond.append((n, e, bound))
         print(f"{tag}: {len(beyond)} of {len(names)} parameters beyond max(1e-3, 3 x fp32 references): {beyond[:6]}")
