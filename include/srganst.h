@@ -333,6 +333,23 @@ int sst_bb_patches(const float* img, float* cand, float* cnrm, int B, int H, int
 int sst_bb_match(const float* sr, const float* cand, const float* cnrm, int* ind, float* dsr, float* partials, int B,
                  int H, int W, int ncand, float alpha, float beta, int criterion_l2, int mode, const float* st_mats,
                  void* stream);
+/* ... with the matching distance of utils.py:157-191 selectable (dist_l1 = 1: sum |x - y|; 0: the clamped expanded squared L2) */
+int sst_bb_match_dist(const float* sr, const float* cand, const float* cnrm, int* ind, float* dsr, float* partials, int B,
+                 int H, int W, int ncand, float alpha, float beta, int criterion_l2, int mode, const float* st_mats, int dist_l1,
+                      void* stream);
+/* General patch geometry for BestBuddyLoss (loss.py:86,116-129: F.unfold with any ksize <= 6, pad, stride; dist_norm 'l1' / 'l2'):
+ * features in global tables [B, rows, D = 3 k k] (unfold order, zero padding).  sst_bbg_patches = F.unfold's patch count;
+ * sst_bbg_unfold fills rows [row_off, row_off + patches) (+ squared norms or null); sst_bbg_match pairs the SR rows srf [B, np, D]
+ * with the candidate table (first np rows = full-resolution GT patches): ind [B, np], gfeat [B, np, D] = d(loss)/d(SR patch entries),
+ * partials [sst_bbg_blocks(B, np)] (loss = their sum); sst_bbg_fold = the unfold's adjoint, d(sr) [B,3,H,W] (overlapping patches summed
+ * in fixed order). */
+int sst_bbg_patches(int H, int W, int k, int pad, int stride);
+int sst_bbg_blocks(int B, int np);
+int sst_bbg_unfold(const float* img, float* table, float* nrm, int B, int H, int W, int k, int pad, int stride, int nrows_total,
+                   int row_off, void* stream);
+int sst_bbg_match(const float* srf, const float* cand, const float* cnrm, int* ind, float* gfeat, float* partials, int B, int np,
+                  int ncand, int D, float alpha, float beta, int criterion_l2, int dist_l1, void* stream);
+int sst_bbg_fold(const float* gfeat, float* dsr, int B, int H, int W, int k, int pad, int stride, void* stream);
 int sst_weighted_sum(const float* const* terms, const float* weights, int n, float* out, float* weighted,
                      void* stream);
 

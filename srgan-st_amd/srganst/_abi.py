@@ -105,6 +105,12 @@ SIGNATURES = {
     "sst_bb_feature_dim": (c_int, [c_int]),
     "sst_bb_patches": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "sst_bb_match": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P]),
+    "sst_bb_match_dist": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, c_int, P]),
+    "sst_bbg_patches": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "sst_bbg_blocks": (c_int, [c_int, c_int]),
+    "sst_bbg_unfold": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_bbg_match": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P]),
+    "sst_bbg_fold": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_weighted_sum": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, P, P, P]),
     "sst_wgrad_c3_supported": (c_int, [c_int, c_int]),
     "sst_wgrad_c3_slab_floats": (c_int64, [c_int, c_int, c_int, c_int]),

@@ -240,12 +240,13 @@ def criterion_sum(sr, gt, terms, weights, ws=None):
 
 
 # ------------------------------------------------------------------------------------------------
-def _torch_bicubic_taps(in_size: int, out_size: int, device):
+def _torch_bicubic_taps(in_size: int, out_size: int, device, scale=None):
     """Tap tables of F.interpolate(mode='bicubic', align_corners=False) (A = -0.75, 4 taps, border indices clamped):
-    -> (weights [out, 4] fp32, indices [out, 4] int32)."""
+    -> (weights [out, 4] fp32, indices [out, 4] int32).  scale: source pixels per output pixel; F.interpolate(scale_factor=f) maps
+    coordinates with 1 / f, not with in_size / out_size (they differ when in_size * f is not an integer)."""
     A = -0.75
     o = torch.arange(out_size, dtype=torch.float64)
-    src = (o + 0.5) * (in_size / out_size) - 0.5
+    src = (o + 0.5) * (float(scale) if scale is not None else in_size / out_size) - 0.5
     x0 = torch.floor(src)
     t = src - x0
 
@@ -260,9 +261,62 @@ def _torch_bicubic_taps(in_size: int, out_size: int, device):
     return w.contiguous().to(device), idx.contiguous().to(device)
 
 
+class _BestBuddyGeneralFn(torch.autograd.Function):
+    """BestBuddyLoss with any patch geometry (ksize <= 6, pad, stride; reference loss.py:86,116-134) and either matching distance
+    (utils.py:157-191): patch tables in global memory (sst_bbg_unfold), tiled matching (sst_bbg_match), the unfold's adjoint for the
+    gradient (sst_bbg_fold) - csrc/bb_loss.hip."""
+
+    @staticmethod
+    def forward(ctx, x, gt, alpha, beta, l2, ksize, pad, stride, dist_l1, cache):
+        if x.dtype != torch.float32 or x.shape != gt.shape or x.dim() != 4 or x.shape[1] != 3:
+            raise _abi.HipPathError("BestBuddyLoss: fp32 [B,3,H,W] pairs")
+        B, _, H, W = x.shape
+        x, gt = x.contiguous(), gt.contiguous()
+        lib, dev = _abi.lib(), x.device
+        sizes = [(H // s, W // s) for s in (1, 2, 4)]                 # F.interpolate(scale_factor=0.5 / 0.25): floor
+        nps = [lib.sst_bbg_patches(h, w, ksize, pad, stride) for h, w in sizes]
+        if min(nps) <= 0:
+            raise _abi.HipPathError(f"BestBuddyLoss: a {ksize}x{ksize} patch (pad {pad}) does not fit the 1/4-resolution image")
+        key = (dev, H, W)
+        if cache.get("key") != key:
+            cache["key"] = key
+            cache["taps"] = [(_torch_bicubic_taps(H, H // s, dev, s), _torch_bicubic_taps(W, W // s, dev, s)) for s in (2, 4)]
+        D, ncand, np_ = 3 * ksize * ksize, sum(nps), nps[0]
+        cand = torch.empty(B, ncand, D, device=dev, dtype=torch.float32)
+        cnrm = torch.empty(B, ncand, device=dev, dtype=torch.float32)
+        st = _abi.stream_ptr()
+        _abi.check(lib.sst_bbg_unfold(_abi.ptr(gt), _abi.ptr(cand), _abi.ptr(cnrm), B, H, W, ksize, pad, stride, ncand, 0, st), "sst_bbg_unfold")
+        off = nps[0]
+        for k, s in enumerate((2, 4)):
+            (wy, iy), (wx, ix) = cache["taps"][k]
+            small = torch.empty(B, 3, H // s, W // s, device=dev, dtype=torch.float32)
+            _abi.check(lib.sst_bicubic(_abi.ptr(gt), _abi.ptr(small), _abi.ptr(wy), _abi.ptr(iy), _abi.ptr(wx), _abi.ptr(ix), B * 3, H, W,
+                                       H // s, W // s, 4, 4, 0, st), "sst_bicubic")
+            _abi.check(lib.sst_bbg_unfold(_abi.ptr(small), _abi.ptr(cand), _abi.ptr(cnrm), B, H // s, W // s, ksize, pad, stride, ncand, off, st),
+                       "sst_bbg_unfold")
+            off += nps[k + 1]
+        srf = torch.empty(B, np_, D, device=dev, dtype=torch.float32)
+        _abi.check(lib.sst_bbg_unfold(_abi.ptr(x), _abi.ptr(srf), None, B, H, W, ksize, pad, stride, np_, 0, st), "sst_bbg_unfold")
+        ind = torch.empty(B, np_, device=dev, dtype=torch.int32)
+        gfeat = torch.empty(B, np_, D, device=dev, dtype=torch.float32)
+        partials = torch.empty(lib.sst_bbg_blocks(B, np_), device=dev, dtype=torch.float32)
+        _abi.check(lib.sst_bbg_match(_abi.ptr(srf), _abi.ptr(cand), _abi.ptr(cnrm), _abi.ptr(ind), _abi.ptr(gfeat), _abi.ptr(partials), B, np_, ncand,
+                                     D, float(alpha), float(beta), int(l2), int(dist_l1), st), "sst_bbg_match")
+        dsr = torch.empty_like(x)
+        _abi.check(lib.sst_bbg_fold(_abi.ptr(gfeat), _abi.ptr(dsr), B, H, W, ksize, pad, stride, st), "sst_bbg_fold")
+        ctx.save_for_backward(dsr)
+        ctx.mark_non_differentiable(ind)
+        return partials.sum(), ind
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_ind):
+        (dsr,) = ctx.saved_tensors
+        return dsr * grad_out, None, None, None, None, None, None, None, None, None
+
+
 class _BestBuddyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gt, alpha, beta, l2, cache, gram=0, st_mats=None):
+    def forward(ctx, x, gt, alpha, beta, l2, cache, gram=0, st_mats=None, dist_l1=0):
         if x.dtype != torch.float32 or x.shape != gt.shape or x.dim() != 4 or x.shape[1] != 3:
             raise _abi.HipPathError("BestBuddyLoss / GramLoss: fp32 [B,3,H,W] pairs")
         B, _, H, W = x.shape
@@ -292,8 +346,8 @@ class _BestBuddyFn(torch.autograd.Function):
         ind = torch.empty(B, nps[0], device=dev, dtype=torch.int32)
         dsr = torch.empty_like(x)
         partials = torch.empty(lib.sst_bb_blocks(B, H, W), device=dev, dtype=torch.float32)
-        _abi.check(lib.sst_bb_match(_abi.ptr(x), _abi.ptr(cand), _abi.ptr(cnrm), _abi.ptr(ind), _abi.ptr(dsr), _abi.ptr(partials), B, H, W,
-                                    ncand, float(alpha), float(beta), int(l2), int(gram), _abi.ptr(st_mats), st), "sst_bb_match")
+        _abi.check(lib.sst_bb_match_dist(_abi.ptr(x), _abi.ptr(cand), _abi.ptr(cnrm), _abi.ptr(ind), _abi.ptr(dsr), _abi.ptr(partials), B, H, W,
+                                         ncand, float(alpha), float(beta), int(l2), int(gram), _abi.ptr(st_mats), int(dist_l1), st), "sst_bb_match")
         ctx.save_for_backward(dsr)
         ctx.mark_non_differentiable(ind)
         return partials.sum(), ind
@@ -301,18 +355,26 @@ class _BestBuddyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _grad_ind):
         (dsr,) = ctx.saved_tensors
-        return dsr * grad_out, None, None, None, None, None, None, None
+        return dsr * grad_out, None, None, None, None, None, None, None, None
+
+
+def _dist_l1(dist_norm: str) -> int:
+    if dist_norm not in ("l1", "l2"):
+        raise NotImplementedError("%s norm has not been supported." % dist_norm)          # utils.py:189
+    return int(dist_norm == "l1")
 
 
 class BestBuddyLoss(nn.Module):
-    """Reference loss.py:78-142 (Best-Buddy GAN loss) on the HIP path.  Same constructor; supported configuration is the
-    reference's default geometry (ksize 3, pad 0, stride 3, dist_norm 'l2') with criterion 'l1' or 'l2' / 'mse'."""
+    """Reference loss.py:78-142 (Best-Buddy GAN loss) on the HIP path.  Same constructor: any ksize (<= 6) / pad / stride and
+    dist_norm 'l1' or 'l2', criterion 'l1' or 'l2' / 'mse'.  The reference's default geometry (ksize 3, pad 0, stride 3, images with
+    H, W multiples of 12) runs the register-resident kernels, everything else the table-based ones (_BestBuddyGeneralFn)."""
 
     def __init__(self, alpha: float = 1.0, beta: float = 1.0, ksize: int = 3, pad: int = 0, stride: int = 3, dist_norm: str = "l2",
                  criterion: str = "l1") -> None:
         super().__init__()
-        if (ksize, pad, stride, dist_norm) != (3, 0, 3, "l2"):
-            raise NotImplementedError("BestBuddyLoss on the HIP path: ksize=3, pad=0, stride=3, dist_norm='l2' only")
+        if not (1 <= int(ksize) <= 6 and int(pad) >= 0 and int(stride) >= 1):
+            raise NotImplementedError("BestBuddyLoss on the HIP path: 1 <= ksize <= 6, pad >= 0, stride >= 1")
+        self._dl1 = _dist_l1(dist_norm)
         if criterion not in ("l1", "l2", "mse"):
             raise NotImplementedError("%s criterion has not been implmented." % criterion)
         self.alpha, self.beta, self.ksize, self.pad, self.stride, self.dist_norm = alpha, beta, ksize, pad, stride, dist_norm
@@ -321,19 +383,26 @@ class BestBuddyLoss(nn.Module):
         self.last_index = None          # [B, n_patches] int32: the selected candidate per SR patch (diagnostics / tests)
 
     def forward(self, x, gt):
-        loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache)
+        default = (self.ksize, self.pad, self.stride) == (3, 0, 3) and x.shape[2] % 12 == 0 and x.shape[3] % 12 == 0
+        if default:
+            loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache, 0, None, self._dl1)
+        else:
+            loss, ind = _BestBuddyGeneralFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, int(self.ksize), int(self.pad),
+                                                  int(self.stride), self._dl1, self._cache)
         self.last_index = ind
         return loss
 
 
 class GramLoss(nn.Module):
     """Reference loss.py:145-228 (best-buddy matching on the 3x3 gram matrix of every 3x3 patch) on the HIP path.  Same
-    constructor; supported: ksize 3, dist_norm 'l2', criterion 'l1' or 'l2' / 'mse'."""
+    constructor; supported: ksize 3 (the reference's reshape to 9 features assumes it, loss.py:200), dist_norm 'l1' or 'l2',
+    criterion 'l1' or 'l2' / 'mse'."""
 
     def __init__(self, alpha: float = 1.0, beta: float = 1.0, ksize: int = 3, dist_norm: str = "l2", criterion: str = "l1") -> None:
         super().__init__()
-        if (ksize, dist_norm) != (3, "l2"):
-            raise NotImplementedError("GramLoss on the HIP path: ksize=3, dist_norm='l2' only")
+        if ksize != 3:
+            raise NotImplementedError("GramLoss on the HIP path: ksize=3 only")
+        self._dl1 = _dist_l1(dist_norm)
         if criterion not in ("l1", "l2", "mse"):
             raise NotImplementedError("%s criterion has not been implmented." % criterion)
         self.alpha, self.beta, self.ksize, self.dist_norm = alpha, beta, ksize, dist_norm
@@ -342,7 +411,7 @@ class GramLoss(nn.Module):
         self.last_index = None
 
     def forward(self, x, gt):
-        loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache, 1)
+        loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache, 1, None, self._dl1)
         self.last_index = ind
         return loss
 
@@ -377,13 +446,14 @@ def _patch_st_matrices(sigma: float, rho: float, device):
 
 class PatchwiseStructureTensorLoss(nn.Module):
     """Reference loss.py:292-375 (best-buddy matching on the normalised structure tensor of every 3x3 patch) on the HIP path.
-    Same constructor; supported: ksize 3, dist_norm 'l2', criterion 'l1' or 'l2' / 'mse'."""
+    Same constructor; supported: ksize 3, dist_norm 'l1' or 'l2', criterion 'l1' or 'l2' / 'mse'."""
 
     def __init__(self, sigma: float = 0.5, rho: float = 2, alpha: float = 1.0, beta: float = 1.0, ksize: int = 3, dist_norm: str = "l2",
                  criterion: str = "l1"):
         super().__init__()
-        if (ksize, dist_norm) != (3, "l2"):
-            raise NotImplementedError("PatchwiseStructureTensorLoss on the HIP path: ksize=3, dist_norm='l2' only")
+        if ksize != 3:
+            raise NotImplementedError("PatchwiseStructureTensorLoss on the HIP path: ksize=3 only")
+        self._dl1 = _dist_l1(dist_norm)
         if criterion not in ("l1", "l2", "mse"):
             raise NotImplementedError("%s criterion has not been supported." % criterion)
         self.sigma, self.rho, self.alpha, self.beta, self.ksize, self.dist_norm = sigma, rho, alpha, beta, ksize, dist_norm
@@ -395,7 +465,7 @@ class PatchwiseStructureTensorLoss(nn.Module):
     def forward(self, x, gt):
         if self._mats is None or self._mats.device != x.device:
             self._mats = _patch_st_matrices(float(self.sigma), float(self.rho), x.device)
-        loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache, 2, self._mats)
+        loss, ind = _BestBuddyFn.apply(x, gt, float(self.alpha), float(self.beta), self.l2, self._cache, 2, self._mats, self._dl1)
         self.last_index = ind
         return loss
 
