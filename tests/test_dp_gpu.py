@@ -134,7 +134,10 @@ def _nccl_worker(port, q):
     # single graphs / split graphs with blocking collectives (round-1 schedule) / overlapped schedule with the graphs cut where a
     # collective goes out (the two D buckets and G's message in flight on RCCL's stream while the next graphs run) / the default with
     # RCCL: ONE graph per iteration with the three collectives captured inside it (DIST.ONE_GRAPH)
-    for force_dp, overlap, one_graph in ((False, False, True), (True, False, True), (True, True, False), (True, True, True)):
+    # ... and the last three again with 8 images per batch: the discriminator step's two passes then run as ONE batch (coefficient
+    # groups) on every one of them
+    for force_dp, overlap, one_graph, nb in ((False, False, True, 2), (True, False, True, 2), (True, True, False, 2), (True, True, True, 2),
+                                             (False, False, True, 8), (True, True, False, 8), (True, True, True, 8)):
         cfg, G = _make(seed=6)
         cfg.DIST.ONE_GRAPH = one_graph
         cfg.add_g_criterion("Pixel", MSELoss(), 1.0)
@@ -146,9 +149,10 @@ def _nccl_worker(port, q):
         assert eng.one_graph_dp == (force_dp and overlap and one_graph) and eng.overlap == (overlap and not eng.one_graph_dp)
         for step in range(4):
             g = torch.Generator().manual_seed(50 + step)           # the discriminator is fixed to 96 x 96 inputs (model.py:31-34)
-            eng.step(torch.rand(2, 3, 96, 96, generator=g).cuda(), torch.rand(2, 3, 24, 24, generator=g).cuda())
+            eng.step(torch.rand(nb, 3, 96, 96, generator=g).cuda(), torch.rand(nb, 3, 24, 24, generator=g).cuda())
         torch.cuda.synchronize()
         assert eng.graph_active, "a hipGraph capture fell back to eager next to a live RCCL communicator"
+        assert eng.d_batched == (nb == 8)
         sd = {"G." + k: v.cpu().numpy() for k, v in G.state_dict().items()}
         sd.update({"D." + k: v.cpu().numpy() for k, v in D.state_dict().items()})
         out.append(sd)
@@ -165,9 +169,11 @@ def test_graph_capture_next_to_rccl_communicator():
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
     p.start()
-    a, b, c, d, e, f = q.get(timeout=300)
+    a, b, c, d, e, f, c8, e8, f8 = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0
+    for k in c8:
+        assert (c8[k] == e8[k]).all() and (c8[k] == f8[k]).all(), k      # the batched discriminator step under the collectives
     for k in a:
         assert (a[k] == b[k]).all(), k           # SRResNet step: all-reduce captured inside the step's graph == single-process graph
     for k in c:
