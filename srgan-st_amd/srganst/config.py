@@ -110,6 +110,10 @@ class Config:
         # the generator's backward starts when the discriminator branch has ended) - 5.80 ms against 5.20 ms for the cut graphs and
         # 4.97 ms single-process (tools/time_dp.py, three discriminator forwards)
         self.DIST.ONE_GRAPH = os.environ.get("SST_DP_ONE_GRAPH", "0") != "0"
+        # overlapped schedule, N > 1, RCCL: the generator's all-reduce on its own communicator (does not queue behind the discriminator's
+        # buckets).  OFF by default: it cannot be exercised here (RCCL needs one GPU per rank, a call has one) and an untested
+        # communicator must not be the first thing a multi-GPU run meets; SST_DP_G_OWN_GROUP=1 to try it on a node
+        self.DIST.G_OWN_GROUP = os.environ.get("SST_DP_G_OWN_GROUP", "0") != "0"
         self.KERNEL = dotdict()
         self.KERNEL.USE_GRAPH = True        # capture the train step into a hipGraph
         self.KERNEL.SYNC_LOSS_EVERY_STEP = False  # reference does .item() per criterion per step (train.py:141)

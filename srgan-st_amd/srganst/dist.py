@@ -8,8 +8,10 @@ optimizer step, so parameters stay bit-identical across ranks.
 Payload: G = 1,547,350 fp32 (6.2 MB) after every G backward; D = 23,563,649 fp32 (94 MB) after
 every D backward.  xGMI is point-to-point, so collectives are per-link bound: few, large,
 flat buffers - G goes out as ONE all-reduce; D as two buckets (classifier 18.9 M / features 4.7 M
-floats).  engine.TrainEngine overlaps them with compute: G's message travels under the discriminator step's forward,
-the classifier bucket under the feature stack's backward (AsyncAllReduce; the collectives run on RCCL's own stream).
+floats).  engine.TrainEngine overlaps them with compute: the classifier bucket travels under the feature stack's backward, the
+generator's message goes out when its backward ends - on the default communicator BEHIND the discriminator's buckets (collectives of
+one process group run in issue order), or on a communicator of its own with DIST.G_OWN_GROUP (off: untested here) - (AsyncAllReduce; the collectives run on the
+process groups' own streams).  All of it is UNMEASURED at N > 1 here (one GPU per call).
 """
 from __future__ import annotations
 

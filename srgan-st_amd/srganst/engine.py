@@ -303,6 +303,13 @@ class TrainEngine:
                              and bool(getattr(config.KERNEL, "OVERLAP_GD", False)))
         if self.one_graph_dp:
             self.overlap = False
+        # The generator's gradient travels on a communicator of its own in the overlapped schedule: on the default one its 6.2 MB
+        # message would queue behind the discriminator's buckets (collectives of one process group run in issue order on one stream)
+        # and hold the generator's Adam until the feature bucket - i.e. the whole discriminator backward - is through.
+        self.pg_g = process_group
+        if self.overlap and self.world > 1 and sdist.is_rccl(process_group) and bool(config.DIST.G_OWN_GROUP):
+            import torch.distributed as td
+            self.pg_g = td.new_group(ranks=list(range(td.get_world_size())) if process_group is None else td.get_process_group_ranks(process_group))
         self._d_a = self._d_b = self._g_f = self._g_b = None
         self.d_batched = False           # set once the discriminator step has run its two passes as one batch (KERNEL.BATCH_D_STEP)
         self.d_sr_reused = False         # set once the discriminator step has run on the generator step's D(sr) pass (KERNEL.REUSE_D_SR)
@@ -818,9 +825,9 @@ class TrainEngine:
                 self._d_b()
                 ar_f = sdist.AsyncAllReduce(self._d_buckets[1], self.pg, force=True)
         self._g_b()
-        ar_g = sdist.AsyncAllReduce(sdist.module_flat_grad(self.G), self.pg, force=True)
+        ar_g = sdist.AsyncAllReduce(sdist.module_flat_grad(self.G), self.pg_g, force=True)
         if ar_g.flat is None:                                    # gradients not in one flat buffer: the generic path
-            sdist.allreduce_module_grads(self.G, self.pg, force=True)
+            sdist.allreduce_module_grads(self.G, self.pg_g, force=True)
         ar_g.wait()
         self._g_op()
         if did_d:
