@@ -130,6 +130,12 @@ int sst_conv_s2_dgrad_pipe_bwdstats(const float* dy, const float* wp, float* dx,
                                     const float* epi_scale, const float* epi_shift, const float* epi_slope,
                                     float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
                                     int Cout, void* stream);
+/* ... with coefficient groups (sst_conv_pipe_fwd_grp): epi_scale / epi_shift [B / grp_images][Cin] */
+int sst_conv_s2_dgrad_pipe_groups_ok(int B, int H, int W, int Cin, int Cout, int grp_images);
+int sst_conv_s2_dgrad_pipe_bwdstats_grp(const float* dy, const float* wp, float* dx, float* ws, const float* epi_y,
+                                    const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                                    float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
+                                    int Cout, int grp_images, void* stream);
 /* stride-1 data-gradient (mode 1 weights) whose epilogue also emits the BatchNorm/activation BACKWARD partial sums of
  * its result g against the saved conv output epi_y: epi_partial [sst_conv_stat_tiles][3][Cout] = per-tile sums of
  * (gz, gz*epi_y, g*min(z,0)) - the layout sst_bwd_finalize consumes (replaces a separate sst_bwd_reduce pass). */

@@ -600,6 +600,10 @@ SST_API int sst_conv_pipe_fwd(const float* x, const float* wp, float* y, const f
 // y = conv3x3(x, stride 2, pad 1); wp = the buffer of sst_conv_s2_dgrad_pack (its 5th section).  Even H, W; Cout % 64 == 0
 // (K blocks), Cin % 32 == 0.
 int64_t sst_conv_s2_dgrad_pipe_section(int Cout, int Cin);      // conv_fwd.hip
+SST_API int sst_conv_s2_dgrad_pipe_bwdstats_grp(const float* dy, const float* wp, float* dx, float* ws, const float* epi_y,
+                                                const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                                                float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
+                                                int Cout, int grp_images, void* stream);
 
 namespace {
 PipePlan pipe_plan_s2d(int B, int H, int W, int Cin, int Cout) {
@@ -644,7 +648,23 @@ SST_API int sst_conv_s2_dgrad_pipe_bwdstats(const float* dy, const float* wp, fl
                                             const float* epi_scale, const float* epi_shift, const float* epi_slope,
                                             float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
                                             int Cout, void* stream) {
+  return sst_conv_s2_dgrad_pipe_bwdstats_grp(dy, wp, dx, ws, epi_y, epi_scale, epi_shift, epi_slope, epi_slope_const, epi_act, epi_partial,
+                                             B, H, W, Cin, Cout, 0, stream);
+}
+// ... with coefficient groups (see sst_conv_pipe_fwd_grp): epi_scale / epi_shift [B / grp_images][Cin], the partial rows of a pass are
+// the p-th of B / grp_images equal consecutive ranges (a tile of the class grid never straddles a pass: sst_conv_s2_dgrad_pipe_groups_ok)
+SST_API int sst_conv_s2_dgrad_pipe_groups_ok(int B, int H, int W, int Cin, int Cout, int grp_images) {
+  const PipePlan pl = pipe_plan_s2d(B, H, W, Cin, Cout);
+  if (!pl.tw || grp_images <= 0 || B % grp_images) return 0;
+  return (grp_images * (H / 2)) % (32 / pl.tw) == 0;
+}
+SST_API int sst_conv_s2_dgrad_pipe_bwdstats_grp(const float* dy, const float* wp, float* dx, float* ws, const float* epi_y,
+                                                const float* epi_scale, const float* epi_shift, const float* epi_slope,
+                                                float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W, int Cin,
+                                                int Cout, int grp_images, void* stream) {
   SST_REQUIRE(dy && wp && dx, "sst_conv_s2_dgrad_pipe: null pointer");
+  SST_REQUIRE(grp_images == 0 || grp_images == B || !epi_partial || sst_conv_s2_dgrad_pipe_groups_ok(B, H, W, Cin, Cout, grp_images),
+              "sst_conv_s2_dgrad_pipe: coefficient groups of %d images do not end on tile boundaries", grp_images);
   SST_REQUIRE(!epi_partial || (epi_y && ((epi_scale == nullptr) == (epi_shift == nullptr))), "sst_conv_s2_dgrad_pipe: backward partials need epi_y");
   const PipePlan pl = pipe_plan_s2d(B, H, W, Cin, Cout);
   SST_REQUIRE(pl.tw, "sst_conv_s2_dgrad_pipe: shape B=%d H=%d W=%d Cin=%d Cout=%d is not taken by the pipelined kernel", B, H, W, Cin, Cout);
@@ -662,7 +682,8 @@ SST_API int sst_conv_s2_dgrad_pipe_bwdstats(const float* dy, const float* wp, fl
 #ifdef SST_PIPE_ABLATE
   a.dbg = 0;
 #endif
-  a.gB = a.grows = 0;                      // the data-gradient's optional epilogue partials take one coefficient row
+  a.gB = (grp_images > 0 && grp_images < B && epi_partial) ? grp_images : 0;
+  a.grows = a.gB * a.Ho;
   const int grid = a.units < 2 * PIPE_CUS ? a.units : 2 * PIPE_CUS;
   hipStream_t st = sst_stream(stream);
 #define SST_S2D_LAUNCH(TW_)                                                                       \

@@ -55,6 +55,8 @@ SIGNATURES = {
     "sst_conv_s2_dgrad_pipe": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_s2_dgrad_pipe_stat_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_s2_dgrad_pipe_bwdstats": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_s2_dgrad_pipe_groups_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sst_conv_s2_dgrad_pipe_bwdstats_grp": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_acc_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_fwd_acc": (c_int, [P, P, P, P, P, P, P, P, c_float, c_int, P, P, P, c_float, c_float, c_float, P, P, P, P, P, P, P,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -325,9 +325,9 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
             # or parameter gradients are wanted (its bias)
             prev = sv["layers"][li - 1] if li > 0 else None
             epi = None
-            if groups == 1 and prev is not None and (prev["bi"] is not None or wg):      # (batched passes: the separate reduce pass takes the groups)
+            if prev is not None and (prev["bi"] is not None or wg):
                 epi = dict(y=prev["y"], scale=prev["scale"], shift=prev["shift"], slope_const=LRELU, act=1)
-            out = ops.conv_s2_dgrad(dy, ws2[f"features.{ci}.weight"], xin.shape[1], xin.shape[2], w.shape[1], epi=epi)
+            out = ops.conv_s2_dgrad(dy, ws2[f"features.{ci}.weight"], xin.shape[1], xin.shape[2], w.shape[1], epi=epi, grp=gB)
             g, part = out if epi is not None else (out, None)
         if li == 0:
             dx = ops.transpose(g, to_nchw=True)

@@ -495,9 +495,10 @@ def pack_conv_s2_dgrad(w, out=None):
 
 
 S2D_EPI = os.environ.get("SST_S2D_EPI", "0") != "0"
+S2D_EPI_GRP = os.environ.get("SST_S2D_EPI_GRP", "0") != "0"      # ... for passes batched as one tall image (grp > 0)
 
 
-def conv_s2_dgrad(dy, wp, H, W, cin, epi=None):
+def conv_s2_dgrad(dy, wp, H, W, cin, epi=None, grp=0):
     """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] for y = conv3x3(x, stride 2, pad 1).
     epi = dict(y, scale, shift, slope, slope_const, act): also the BatchNorm / activation backward partials of dx against epi["y"]
     ([tiles,3,cin], the layout bwd_finalize consumes) where the pipelined kernel takes the shape -> (dx, partial | None)."""
@@ -510,19 +511,21 @@ def conv_s2_dgrad(dy, wp, H, W, cin, epi=None):
         partial = None
         # measured on the G + D + ST step: 5.34 ms with the partials in the epilogue against 5.30 ms with the separate reduce pass (four
         # scattered epilogues per unit cost more than the three reduce launches they replace) - off unless SST_S2D_EPI=1
-        if epi is not None and S2D_EPI:
+        grouped = bool(grp) and grp < B
+        if epi is not None and ((S2D_EPI and not grouped) or
+                                (grouped and S2D_EPI_GRP and L.sst_conv_s2_dgrad_pipe_groups_ok(B, H, W, cin, cout, int(grp)))):
             partial = _f32(L.sst_conv_s2_dgrad_pipe_stat_tiles(B, H, W, cin, cout), 3, cin, like=dy)
         e = epi or {}
         args = (ptr(dy), ptr(wp), ptr(dx), ptr(ws), ptr(e.get("y")) if partial is not None else None,
                 ptr(e.get("scale")) if partial is not None else None, ptr(e.get("shift")) if partial is not None else None,
                 ptr(e.get("slope")) if partial is not None else None, float(e.get("slope_const", 0.0)), int(e.get("act", 0)),
-                ptr(partial), B, H, W, cin, cout)
+                ptr(partial), B, H, W, cin, cout, int(grp) if partial is not None else 0)
         e0 = _prof_begin()
-        check(L.sst_conv_s2_dgrad_pipe_bwdstats(*args, stream_ptr()), "sst_conv_s2_dgrad_pipe")
+        check(L.sst_conv_s2_dgrad_pipe_bwdstats_grp(*args, stream_ptr()), "sst_conv_s2_dgrad_pipe")
         if PROFILE is not None or TRACE is not None:
             name, flops = f"conv_pipe_kernel<1, {L.sst_conv_s2_dgrad_pipe_supported(B, H, W, cin, cout)}, 1>", 2.0 * B * ho * wo * cout * cin * 9
             _prof_end(e0, name, flops)
-            _trace(name, flops, lambda: L.sst_conv_s2_dgrad_pipe_bwdstats(*args, stream_ptr()), dy, wp, dx, ws, partial,
+            _trace(name, flops, lambda: L.sst_conv_s2_dgrad_pipe_bwdstats_grp(*args, stream_ptr()), dy, wp, dx, ws, partial,
                    e.get("y"), e.get("scale"), e.get("shift"), e.get("slope"))
         return (dx, partial) if epi is not None else dx
     e0 = _prof_begin()
