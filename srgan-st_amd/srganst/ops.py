@@ -143,6 +143,9 @@ def conv_pipe_groups_ok(B, H, W, cin, cout, ksize, stride, grp):
         bool(_abi.lib().sst_conv_pipe_groups_ok(B, H, W, cin, cout, ksize, stride, int(grp)))
 
 
+CONV_NS = os.environ.get("SST_CONV_NS", "1") != "0"      # the N-split form of the pipelined conv where it applies (0: dev A/B)
+
+
 def _conv_pipe(x, wp, y, cout, ksize, stride, bias=None, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,
                in_act=ACT_NONE, want_stats=False, epi=None, grp=0):
     """sst_conv_pipe_fwd: forward statistics (want_stats) or backward partials (epi = dict(y, scale, shift, slope, slope_const,
@@ -157,6 +160,20 @@ def _conv_pipe(x, wp, y, cout, ksize, stride, bias=None, in_scale=None, in_shift
     e = epi or {}
     if epi is not None:
         partial = _f32(L.sst_conv_pipe_stat_tiles(*shp), 3, cout, like=x)
+    if CONV_NS and L.sst_conv_ns_supported(*shp):
+        # the N-split form (csrc/conv_nsplit.hip): same tiling, statistics rows and packed weights, no split-K workspace
+        nargs = (ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const), int(in_act),
+                 ptr(stats), ptr(cnt), ptr(e.get("y")), ptr(e.get("scale")), ptr(e.get("shift")), ptr(e.get("slope")),
+                 float(e.get("slope_const", 0.0)), int(e.get("act", 0)), ptr(partial), *shp, int(grp))
+        e0 = _prof_begin()
+        check(L.sst_conv_ns_fwd(*nargs, stream_ptr()), "sst_conv_ns_fwd")
+        ho, wo = conv_out_hw(H, W, ksize, stride)
+        flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
+        name = f"conv_ns_kernel<{stride}, {L.sst_conv_ns_supported(*shp)}>" if (PROFILE is not None or TRACE is not None) else ""
+        _prof_end(e0, name, flops)
+        _trace(name, flops, lambda: L.sst_conv_ns_fwd(*nargs, stream_ptr()),
+               x, wp, y, bias, in_scale, in_shift, in_slope, stats, cnt, partial, *[v for v in e.values() if torch.is_tensor(v)])
+        return y, stats, cnt, partial
     nws = L.sst_conv_pipe_ws_floats(*shp)
     ws = _f32(nws, like=x) if nws else None
     args = (ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const), int(in_act),

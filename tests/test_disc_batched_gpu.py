@@ -127,10 +127,17 @@ def _make_d(seed=3):
     return cfg, Discriminator(cfg).cuda().train()
 
 
-def test_discriminator_two_passes_as_one_batch():
+@pytest.mark.parametrize("same_kernels", [True, False])
+def test_discriminator_two_passes_as_one_batch(same_kernels, monkeypatch):
     """disc_graph.forward on [a, b] (one tall image, per-pass statistics) + ONE backward over 2B images against two sequential passes
-    (second one accumulating): logits, every saved coefficient row, running statistics / counters, every parameter gradient."""
+    (second one accumulating): logits, every saved coefficient row, running statistics / counters, every parameter gradient.
+    same_kernels: the N-split conv (which takes a layer by its number of tiles, so the 2B-image pass and the B-image pass can land on
+    different kernels) is switched off, both sides sum in the same order and the gradients must agree to 2e-4; with the product's
+    routing the two sides are two fp32 summation orders of the discriminator's ill-conditioned BatchNorm gradients (see the
+    iteration test below for the fp64-truth rule) and the bound is 2e-3."""
     from srganst import disc_graph, ops
+    if same_kernels:
+        monkeypatch.setattr(ops, "CONV_NS", False)
     B = 8
     gen = torch.Generator().manual_seed(9)
     a, b = torch.rand(B, 3, 96, 96, generator=gen).cuda(), torch.rand(B, 3, 96, 96, generator=gen).cuda()
@@ -168,7 +175,7 @@ def test_discriminator_two_passes_as_one_batch():
     assert int(sdb["features.3.num_batches_tracked"]) == 2
     worst = max((rel_err(gb[n], gs[n]), n) for n in gs)
     print("worst gradient difference batched vs sequential:", worst)
-    assert worst[0] < 2e-4, worst
+    assert worst[0] < (2e-4 if same_kernels else 2e-3), worst
 
 
 @pytest.mark.parametrize("reuse", [False, True])
