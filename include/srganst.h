@@ -115,16 +115,18 @@ int sst_conv_pipe_fwd_grp(const float* x, const float* wp, float* y, const float
                           float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
                           const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, float* ws, int B,
                           int H, int W, int Cin, int Cout, int ksize, int stride, int grp_images, void* stream);
-/* "N-split" form of the pipelined kernel (csrc/conv_nsplit.hip) for Cout % 128 == 0 and at least 512 (tile, 128-channel group) units:
+/* "N-split" form of the pipelined kernel (csrc/conv_nsplit.hip) for Cout % 128 == 0 and at least 1024 (tile, 128-channel group) units
+ * (512 with out_mode = 1, the PixelShuffle(2) store of sst_conv_fwd - model.py:160 - which the K-split kernel does not have; no
+ * statistics / partials with it):
  * the 4 waves of a workgroup share one staged patch and each computes the full K for its own 32 output channels - no K-partial
  * exchange, a quarter of the patch traffic per MFMA.  Same arguments, packed weights and statistics tiling as sst_conv_pipe_fwd_grp
  * (no split-K workspace); sst_conv_ns_supported: tile width when the shape is taken, else 0. */
-int sst_conv_ns_supported(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int sst_conv_ns_supported(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int out_mode);
 int sst_conv_ns_fwd(const float* x, const float* wp, float* y, const float* bias, const float* in_scale,
                     const float* in_shift, const float* in_slope, float in_slope_const, int in_act, float* stats,
                     float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
                     const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W,
-                    int Cin, int Cout, int ksize, int stride, int grp_images, void* stream);
+                    int Cin, int Cout, int ksize, int stride, int out_mode, int grp_images, void* stream);
 /* stride-2 data-gradient (sst_conv_s2_dgrad below) on the pipelined kernel: the four parity classes of a block of class pixels in
  * one unit (they share the dY patch), the 9 (class, tap) pairs in the place of the 9 taps, one accumulator per class.  Even H, W;
  * Cout % 64 == 0, Cin % 32 == 0.  wp = the buffer of sst_conv_s2_dgrad_pack; ws = sst_conv_s2_dgrad_pipe_ws_floats floats (0: none).

@@ -26,6 +26,8 @@ namespace {
 constexpr int NS_RING = 9;
 constexpr int NS_PSTR = CB + 4;      // floats per patch pixel in LDS (64 channels + 4 pad: 16-B aligned rows, conflict-free b128 reads)
 
+constexpr int OUT_NHWC = 0, OUT_SHUFFLE = 1;             // the two stores of conv_epilogue.h's list this kernel has
+
 struct NsArgs {
   const float* x; const float* wp; float* y; const float* bias;
   const float* in_scale; const float* in_shift; const float* in_slope; float in_slope_const; int in_act;
@@ -35,6 +37,7 @@ struct NsArgs {
   int B, H, W, Cin, Cout, Ho, Wo, R;
   int tiles_x, n_mt, nfg, ncb, units;
   int gB, grows;
+  int shuffle;                                          // OUT_SHUFFLE store (PixelShuffle(2) of the result, conv_common.h)
 };
 
 template <int S, int TW>
@@ -239,7 +242,9 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_ns_kernel(NsArgs a) {
         const int pi = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int rr = r0 + pi / TW, ox = ox0 + pi % TW;
         ok[r] = rr < a.R;
-        off[r] = (rr * a.Wo + ox) * a.Cout + co;
+        // OUT_SHUFFLE: output channel co = 4c + 2i + j lands at row 2 rr + i (tall image: 2 (b Ho + oy) + i), column 2 ox + j, channel c
+        off[r] = a.shuffle ? ((2 * rr + ((co >> 1) & 1)) * (2 * a.Wo) + 2 * ox + (co & 1)) * (a.Cout >> 2) + (co >> 2)
+                           : (rr * a.Wo + ox) * a.Cout + co;
         v[r] = acc[r] + bv;
         acc[r] = 0.f;
         if (ok[r]) a.y[off[r]] = v[r];
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(CONV_NT, 2) void conv_ns_kernel(NsArgs a) {
 
 struct NsPlan { int tw, n_mt, tiles_x, nfg, ncb; };
 
-NsPlan ns_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+NsPlan ns_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int out_mode = OUT_NHWC) {
   NsPlan pl{};
   if (ksize != 3 || (stride != 1 && stride != 2) || (Cin % 64) || (Cout % 128) || B <= 0) return pl;
   if (stride == 2 && ((H | W) & 1)) return pl;
@@ -325,15 +330,17 @@ NsPlan ns_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
   // measured against conv_pipe_kernel (tools/time_pipe.py): 2,304 / 1,152 units 93.7 vs 117.5 us, 51.0 vs 61.3, 91.1 vs 101.4 (116-119 TF/s
   // = 74-76 % of the fp32 MFMA peak); 576 units 103.5 vs 92.5, 104.7 vs 95.3, 55.7 vs 53.6: a unit is 4x longer here, with fewer than
   // ~4 per CU the tail costs more than the exchange it saves - those layers stay on the K-split kernel
-  if ((long)pl.n_mt * pl.nfg < 1024) return pl;
+  // (the pixel-shuffle store has no K-split kernel to fall back to: the general 32 x 32-tile kernel runs those layers at 42-55 %)
+  if (out_mode != OUT_NHWC && out_mode != OUT_SHUFFLE) return pl;
+  if ((long)pl.n_mt * pl.nfg < (out_mode == OUT_SHUFFLE ? 512 : 1024)) return pl;
   pl.tw = tw;
   return pl;
 }
 
 }  // namespace
 
-SST_API int sst_conv_ns_supported(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
-  return ns_plan(B, H, W, Cin, Cout, ksize, stride).tw;
+SST_API int sst_conv_ns_supported(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int out_mode) {
+  return ns_plan(B, H, W, Cin, Cout, ksize, stride, out_mode).tw;
 }
 
 // Arguments as sst_conv_pipe_fwd_grp (no split-K workspace); stats / stats_cnt / epi_partial have sst_conv_pipe_stat_tiles rows (the
@@ -342,9 +349,10 @@ SST_API int sst_conv_ns_fwd(const float* x, const float* wp, float* y, const flo
                             const float* in_shift, const float* in_slope, float in_slope_const, int in_act, float* stats,
                             float* stats_cnt, const float* epi_y, const float* epi_scale, const float* epi_shift,
                             const float* epi_slope, float epi_slope_const, int epi_act, float* epi_partial, int B, int H, int W,
-                            int Cin, int Cout, int ksize, int stride, int grp_images, void* stream) {
+                            int Cin, int Cout, int ksize, int stride, int out_mode, int grp_images, void* stream) {
   SST_REQUIRE(x && wp && y, "sst_conv_ns_fwd: null pointer");
-  const NsPlan pl = ns_plan(B, H, W, Cin, Cout, ksize, stride);
+  const NsPlan pl = ns_plan(B, H, W, Cin, Cout, ksize, stride, out_mode);
+  SST_REQUIRE(out_mode == OUT_NHWC || (!stats && !epi_partial), "sst_conv_ns_fwd: statistics / backward partials need the NHWC store");
   SST_REQUIRE(pl.tw, "sst_conv_ns_fwd: shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d stride=%d is not taken by the N-split kernel", B, H, W, Cin,
               Cout, ksize, stride);
   SST_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sst_conv_ns_fwd: in_scale/in_shift must come together");
@@ -366,6 +374,7 @@ SST_API int sst_conv_ns_fwd(const float* x, const float* wp, float* y, const flo
   a.tiles_x = pl.tiles_x; a.n_mt = pl.n_mt; a.nfg = pl.nfg; a.ncb = pl.ncb; a.units = pl.n_mt * pl.nfg;
   a.gB = (grp_images > 0 && grp_images < B) ? grp_images : 0;
   a.grows = a.gB * a.Ho;
+  a.shuffle = out_mode == OUT_SHUFFLE;
   const int wg_per_cu = stride == 1 ? 3 : 2;      // register-limited (149-161 / 196-212 VGPRs)
   const int grid = a.units < wg_per_cu * 256 ? a.units : wg_per_cu * 256;
   hipStream_t st = sst_stream(stream);

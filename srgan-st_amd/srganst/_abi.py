@@ -50,9 +50,9 @@ SIGNATURES = {
     "sst_conv_pipe_groups_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_pipe_fwd_grp": (c_int, [P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, c_float, c_int, P, P,
                                       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "sst_conv_ns_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sst_conv_ns_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_ns_fwd": (c_int, [P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, P, P, c_float, c_int, P,
-                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sst_conv_s2_dgrad_pipe_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_s2_dgrad_pipe_ws_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "sst_conv_s2_dgrad_pipe": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -111,6 +111,12 @@ def conv_fwd(x, wp, cout, ksize=3, stride=1, bias=None, in_scale=None, in_shift=
         y, stats, cnt, _ = _conv_pipe(x, wp, y, cout, ksize, stride, bias, in_scale, in_shift, in_slope, in_slope_const, in_act,
                                       want_stats, grp=grp)
         return y, None, stats, cnt
+    if (out_mode == OUT_SHUFFLE and residual is None and not want_pre and not want_stats and CONV_NS
+            and _abi.lib().sst_conv_ns_supported(B, H, W, cin, cout, ksize, stride, OUT_SHUFFLE)):
+        # the up-sampling blocks' convs (model.py:157-161): N-split kernel with the PixelShuffle store
+        y, _, _, _ = _conv_pipe(x, wp, y, cout, ksize, stride, bias, in_scale, in_shift, in_slope, in_slope_const, in_act, False,
+                                out_mode=OUT_SHUFFLE)
+        return y, None, None, None
     y_pre = torch.empty_like(y) if want_pre else None
     stats = cnt = None
     if want_stats:
@@ -147,7 +153,7 @@ CONV_NS = os.environ.get("SST_CONV_NS", "1") != "0"      # the N-split form of t
 
 
 def _conv_pipe(x, wp, y, cout, ksize, stride, bias=None, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,
-               in_act=ACT_NONE, want_stats=False, epi=None, grp=0):
+               in_act=ACT_NONE, want_stats=False, epi=None, grp=0, out_mode=OUT_NHWC):
     """sst_conv_pipe_fwd: forward statistics (want_stats) or backward partials (epi = dict(y, scale, shift, slope, slope_const,
     act)); returns (y, stats, cnt, partial)."""
     B, H, W, cin = x.shape
@@ -160,20 +166,21 @@ def _conv_pipe(x, wp, y, cout, ksize, stride, bias=None, in_scale=None, in_shift
     e = epi or {}
     if epi is not None:
         partial = _f32(L.sst_conv_pipe_stat_tiles(*shp), 3, cout, like=x)
-    if CONV_NS and L.sst_conv_ns_supported(*shp):
+    if CONV_NS and L.sst_conv_ns_supported(*shp, int(out_mode)):
         # the N-split form (csrc/conv_nsplit.hip): same tiling, statistics rows and packed weights, no split-K workspace
         nargs = (ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const), int(in_act),
                  ptr(stats), ptr(cnt), ptr(e.get("y")), ptr(e.get("scale")), ptr(e.get("shift")), ptr(e.get("slope")),
-                 float(e.get("slope_const", 0.0)), int(e.get("act", 0)), ptr(partial), *shp, int(grp))
+                 float(e.get("slope_const", 0.0)), int(e.get("act", 0)), ptr(partial), *shp, int(out_mode), int(grp))
         e0 = _prof_begin()
         check(L.sst_conv_ns_fwd(*nargs, stream_ptr()), "sst_conv_ns_fwd")
         ho, wo = conv_out_hw(H, W, ksize, stride)
         flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
-        name = f"conv_ns_kernel<{stride}, {L.sst_conv_ns_supported(*shp)}>" if (PROFILE is not None or TRACE is not None) else ""
+        name = f"conv_ns_kernel<{stride}, {L.sst_conv_ns_supported(*shp, int(out_mode))}>" if (PROFILE is not None or TRACE is not None) else ""
         _prof_end(e0, name, flops)
         _trace(name, flops, lambda: L.sst_conv_ns_fwd(*nargs, stream_ptr()),
                x, wp, y, bias, in_scale, in_shift, in_slope, stats, cnt, partial, *[v for v in e.values() if torch.is_tensor(v)])
         return y, stats, cnt, partial
+    assert out_mode == OUT_NHWC
     nws = L.sst_conv_pipe_ws_floats(*shp)
     ws = _f32(nws, like=x) if nws else None
     args = (ptr(x), ptr(wp), ptr(y), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const), int(in_act),

@@ -122,6 +122,29 @@ def test_conv_shuffle_and_clamp_stores(ops):
     assert rel_err(nchw(yu.cpu()), F.pixel_unshuffle(ref, 2)) < TOL
 
 
+@pytest.mark.parametrize("case", [(16, 24, 24), (4, 48, 48), (5, 42, 48)])
+def test_conv_shuffle_store_nsplit_kernel(ops, case, monkeypatch):
+    """The up-sampling blocks' convs (model.py:157-161: 64 -> 256, PixelShuffle(2), PReLU applied by the consumer) at sizes the N-split
+    kernel takes (csrc/conv_nsplit.hip, OUT_SHUFFLE store; bias, PReLU on the input as the second block sees it): against torch in
+    fp64, and against the general kernel's store of the same layer."""
+    from srganst import _abi
+    B, H, W = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(256, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(256, generator=g) * 0.1
+    slope = torch.tensor([0.25])
+    assert _abi.lib().sst_conv_ns_supported(B, H, W, 64, 256, 3, 1, ops.OUT_SHUFFLE)
+    ref = F.pixel_shuffle(F.conv2d(F.prelu(x.double(), slope.double()), w.double(), b.double(), 1, 1), 2)
+    wp = ops.pack_conv(w.cuda())
+    kw = dict(bias=b.cuda(), in_slope=slope.cuda(), in_act=ops.ACT_SLOPE, out_mode=ops.OUT_SHUFFLE)
+    y, _, _, _ = ops.conv_fwd(nhwc(x).cuda(), wp, 256, 3, 1, **kw)
+    assert tuple(y.shape) == (B, 2 * H, 2 * W, 64) and rel_err(nchw(y.cpu()), ref) < TOL
+    monkeypatch.setattr(ops, "CONV_NS", False)
+    y0, _, _, _ = ops.conv_fwd(nhwc(x).cuda(), wp, 256, 3, 1, **kw)
+    assert rel_err(y, y0) < 1e-5
+
+
 @pytest.mark.parametrize("case", [(2, 24, 24, 64, 64, 3), (1, 13, 9, 8, 8, 3), (1, 16, 16, 64, 256, 3), (1, 16, 16, 256, 64, 3),
                                   (1, 20, 12, 64, 3, 9)])
 def test_conv_dgrad_via_mode1_pack(ops, case):
