@@ -208,6 +208,12 @@ int sst_conv_wgrad_grp(const float* x, const float* dy, float* slab, float* dw, 
                    const float* in_shift, const float* in_slope, float in_slope_const, int in_act,
                    int B, int H, int W, int Cin, int Cout, int stride, int ksize, int accumulate,
                        int grp_images, void* stream);
+/* Slab reduces of a whole backward pass in one launch: sst_conv_wgrad_grp with accumulate bit 2 (value 4) leaves its slab un-reduced
+ * where sst_conv_wgrad_pending_reduce(...) > 0 (= the slab's chunk count; 0: that launch writes dW itself and ignores the bit); the
+ * caller then hands sst_wgrad_reduce_multi a HOST array of up to 24 jobs {const float* slab; float* dw; int nchunk, kk, Cout, Cin,
+ * accumulate, reserved;} (40 bytes each).  Same arithmetic per job as the per-layer reduce (bit-identical dW). */
+int sst_conv_wgrad_pending_reduce(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int has_in_scale, int in_act);
+int sst_wgrad_reduce_multi(const void* jobs, int njobs, void* stream);
 /* weight gradient of the two 9x9 convs with a 3-channel side (Generator.conv1 / conv3, model.py:101,127):
  * N = (kx, ch3) = 27 of 32 MFMA columns instead of 3.  kind 0 = conv3 (C->3), kind 1 = conv1 (3->C). */
 int sst_wgrad_c3_supported(int C, int ksize);

@@ -700,6 +700,74 @@ static void launch_wgrad_reduce(const float* slab, float* dw, int nchunk, int KK
   wgrad_reduce_kernel<<<dim3(rb, njobs), 256, 0, st>>>(slab, dw, nchunk, KK, Cout, Cin, accumulate, grouped, t);
 }
 
+// ---- slab reduces of several layers (any shapes) in ONE launch: the weight gradients of a backward pass are leaves of its chain, so
+// their reduces can wait for the end of the pass (sst_conv_wgrad_grp with accumulate bit 2 leaves the slab alone) and go out together -
+// one launch that fills the chip instead of 5-10 us of a few workgroups behind every layer's weight gradient.  Per job the arithmetic
+// is launch_wgrad_reduce's (same variant by the same rule, same chunk order): bit-identical to the per-layer reduce.
+namespace {
+struct WrJob { const float* slab; float* dw; int nchunk, KK, Cout, Cin, accumulate, blocks; };
+constexpr int WR_TAB_MAX = 24;
+struct WrJobTab { WrJob j[WR_TAB_MAX]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WrJobTab tab) {
+  const WrJob jb = tab.j[blockIdx.y];
+  if ((int)blockIdx.x >= jb.blocks) return;
+  const float* __restrict__ slab = jb.slab;
+  float* __restrict__ dw = jb.dw;
+  const int nchunk = jb.nchunk, KK = jb.KK, accumulate = jb.accumulate & 1;
+  const int64_t per_tap = (int64_t)jb.Cout * jb.Cin, total = per_tap * KK;
+  if ((jb.Cin & 3) == 0 && nchunk >= 8) {                  // split variant (wgrad_reduce_kernel)
+    __shared__ f32x4 part[4][64];
+    const int item = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int64_t i4 = blockIdx.x * 64ll + item, total4 = total >> 2;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < total4) {
+#pragma unroll 4
+      for (int s = cg; s < nchunk; s += 4) t += *reinterpret_cast<const f32x4*>(slab + (size_t)s * total + (i4 << 2));
+    }
+    part[cg][item] = t;
+    __syncthreads();
+    if (cg == 0 && i4 < total4) {
+      t = ((part[0][item] + part[1][item]) + part[2][item]) + part[3][item];
+      const int64_t i = i4 << 2;
+      const int tap = (int)(i / per_tap);
+      const int64_t oc = i - (int64_t)tap * per_tap;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* d = dw + (oc + j) * KK + tap;
+        *d = accumulate ? *d + t[j] : t[j];
+      }
+    }
+    return;
+  }
+  if ((jb.Cin & 3) == 0) {
+    const int64_t total4 = total >> 2;
+    for (int64_t i4 = blockIdx.x * 256ll + threadIdx.x; i4 < total4; i4 += (int64_t)jb.blocks * 256) {
+      const int64_t i = i4 << 2;
+      const int tap = (int)(i / per_tap);
+      const int64_t oc = i - (int64_t)tap * per_tap;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int s = 0; s < nchunk; ++s) t += *reinterpret_cast<const f32x4*>(slab + (size_t)s * total + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* d = dw + (oc + j) * KK + tap;
+        *d = accumulate ? *d + t[j] : t[j];
+      }
+    }
+  } else {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)jb.blocks * 256) {
+      const int tap = (int)(i / per_tap);
+      const int64_t oc = i - (int64_t)tap * per_tap;
+      float t = 0.f;
+#pragma unroll 8
+      for (int s = 0; s < nchunk; ++s) t += slab[(size_t)s * total + i];
+      float* d = dw + oc * KK + tap;
+      *d = accumulate ? *d + t : t;
+    }
+  }
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // 3x3 / STRIDE-2 / pad-1 weight gradient, ALL 9 TAPS per wave (discriminator layers 2 / 4 / 6 / 8, reference model.py:34-59).
 //   dW[co][ci][ky][kx] = sum_{b,oy,ox} dY[b,oy,ox,co] * act(X)[b, 2oy+ky-1, 2ox+kx-1, ci]
@@ -1121,8 +1189,49 @@ SST_API int sst_conv_wgrad_grp(const float* x, const float* dy, float* slab, flo
   else
     conv_wgrad_kernel<false><<<grid, CONV_NT, 0, sst_stream(stream)>>>(a, no_tab);
   SST_LAUNCH_CHECK("conv_wgrad_kernel");
+  if (accumulate & 4) return SST_OK;             // the caller reduces the slab later (sst_wgrad_reduce_multi)
   launch_wgrad_reduce(slab, dw, nchunk, KK, Cout, Cin, accumulate, nullptr, 1, sst_stream(stream));
   SST_LAUNCH_CHECK("wgrad_reduce_kernel");
+  return SST_OK;
+}
+
+// Chunks of slab that sst_conv_wgrad_grp leaves for sst_wgrad_reduce_multi when called with accumulate bit 2 (value 4) for this shape;
+// 0: the launch writes dW itself (single-chunk tile kernel, 3-channel MFMA kernel with its own reduce) and the bit changes nothing.
+SST_API int sst_conv_wgrad_pending_reduce(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int has_in_scale, int in_act) {
+  const WgS2Plan p2 = wgrad_s2_plan(B, H, W, Cin, Cout, ksize, stride);
+  if (p2.th) return (p2.nchunk == 1 && !sst_env("SST_WGRAD_TILE_NO_DIRECT")) ? 0 : p2.nchunk;
+  const WgBandPlan pl = wgrad_band_plan(B, H, W, Cin, Cout, ksize, stride, 1);
+  if (pl.R) return pl.nchunk;
+  static const float one = 0.f;
+  const bool c3 = k3c3_applies(Cin, ksize, stride, has_in_scale ? &one : nullptr, in_act);
+  if (c3 && k3c3_mfma_applies(W, Cout)) return 0;
+  if (c3 && !sst_env("SST_WGRAD_NO_K3C3")) return B * ((H + C3_ROWS - 1) / C3_ROWS);
+  const int pad = ksize / 2;
+  return sst_conv_wgrad_chunks(B, (H + 2 * pad - ksize) / stride + 1, (W + 2 * pad - ksize) / stride + 1, Cin, Cout, ksize);
+}
+
+// jobs: HOST array of njobs <= 24 records {slab, dw, nchunk, k*k, Cout, Cin, accumulate, 0} (two pointers + six ints = 40 bytes):
+// dW[co][ci][tap] (+)= sum over the job's nchunk slab chunks, every job in one launch.
+SST_API int sst_wgrad_reduce_multi(const void* jobs, int njobs, void* stream) {
+  static_assert(sizeof(WrJob) == 40, "WrJob layout");
+  SST_REQUIRE(jobs && njobs > 0 && njobs <= WR_TAB_MAX, "sst_wgrad_reduce_multi: 1..%d jobs", WR_TAB_MAX);
+  WrJobTab tab{};
+  memcpy(tab.j, jobs, (size_t)njobs * sizeof(WrJob));
+  int maxb = 0;
+  for (int i = 0; i < njobs; ++i) {
+    WrJob& j = tab.j[i];
+    SST_REQUIRE(j.slab && j.dw && j.nchunk > 0 && j.KK > 0 && j.Cout > 0 && j.Cin > 0, "sst_wgrad_reduce_multi: bad job %d", i);
+    const int64_t total = (int64_t)j.KK * j.Cout * j.Cin;
+    if ((j.Cin & 3) == 0 && j.nchunk >= 8) {
+      j.blocks = (int)((total / 4 + 63) / 64);
+    } else {
+      const int64_t items = (j.Cin & 3) == 0 ? total / 4 : total;
+      j.blocks = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
+    }
+    if (j.blocks > maxb) maxb = j.blocks;
+  }
+  wgrad_reduce_multi_kernel<<<dim3(maxb, njobs), 256, 0, sst_stream(stream)>>>(tab);
+  SST_LAUNCH_CHECK("wgrad_reduce_multi_kernel");
   return SST_OK;
 }
 

@@ -78,6 +78,8 @@ SIGNATURES = {
     "sst_conv_wgrad_grp": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_int, P]),
     "sst_conv_wgrad_grouped": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sst_conv_wgrad_pending_reduce": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sst_wgrad_reduce_multi": (c_int, [P, c_int, P]),
     "sst_bn_finalize": (c_int, [P, P, c_int, c_int, P, P, P, P, P, P, P, P, c_float, c_float, P]),
     "sst_bn_finalize_grp": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_float, c_float, P]),
     "sst_bn_eval_affine": (c_int, [P, P, P, P, P, P, c_int, c_float, P]),

@@ -276,6 +276,7 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
     groups, gB = sv.get("groups", 1), sv.get("gB", 0)      # passes batched as one tall image: per-pass coefficient rows
     wd, ws2 = sv["wd"], sv["ws2"]               # packed (or re-used) by the forward
     part = None                      # BN/activation backward partials of g, when the producing dgrad conv emitted them
+    reduces = [] if ops.WGRAD_REDUCE_MULTI else None      # slab reduces left for one launch at the end of the pass
     for li in reversed(range(len(sv["layers"]))):
         r = sv["layers"][li]
         y = r["y"]
@@ -298,16 +299,16 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
         if wg:
             dwc = G(f"features.{ci}.weight")
 
-            def launch(r=r, dy=dy, dwc=dwc):
+            def launch(r=r, dy=dy, dwc=dwc, red=None):
                 ops.conv_wgrad(r["x"], dy, dwc, 3, r["stride"], in_scale=r["x_scale"], in_shift=r["x_shift"],
-                               in_slope_const=LRELU, in_act=r["x_act"], accumulate=acc, grp=gB)
+                               in_slope_const=LRELU, in_act=r["x_act"], accumulate=acc, grp=gB, defer_reduce=red)
             if defer_wgrad is not None and (defer_below is None or li < defer_below):
                 ev = torch.cuda.Event()
                 ev.record()
                 defer_wgrad.append((ev, launch, (r["x"], dy, dwc, r["x_scale"], r["x_shift"])))
             else:
                 with ops.SideStream(r["x"], dy, dwc):
-                    launch()
+                    launch(red=reduces)
         if li == 0 and not need_dx:
             break
         xin = r["x"]
@@ -331,6 +332,10 @@ def backward_features(module, p, sv, st, need_param_grads, need_dx, defer_wgrad=
             g, part = out if epi is not None else (out, None)
         if li == 0:
             dx = ops.transpose(g, to_nchw=True)
+    if reduces:
+        # the weight gradients' slab reduces (leaves of the chain), all layers in one launch - on the stream the weight gradients ran on
+        with ops.SideStream(*[t for j in reduces for t in j[:2]]):
+            ops.wgrad_reduce_flush(reduces)
     ops.join_side()
     if acc:
         grads = {}                   # already added into the first pass's buffer

@@ -307,9 +307,11 @@ def bn_finalize_acc(acc, n, gamma, beta, run_mean=None, run_var=None):
 
 
 def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, in_slope=None, in_slope_const=0.0,
-               in_act=ACT_NONE, accumulate=False, grp=0):
+               in_act=ACT_NONE, accumulate=False, grp=0, defer_reduce=None):
     """dw_out [Cout,Cin,k,k] (reference layout) (+)= wgrad.  x [B,H,W,Cin], dy [B,Ho,Wo,Cout] NHWC.
-    grp > 0: B / grp passes of grp images, in_scale / in_shift [B / grp, Cin] (all-taps tile kernel only)."""
+    grp > 0: B / grp passes of grp images, in_scale / in_shift [B / grp, Cin] (all-taps tile kernel only).
+    defer_reduce (a list): where the launch ends in a slab reduce, the reduce is not launched but appended as a job for
+    wgrad_reduce_flush (one launch for all the layers of a backward pass); dw_out is complete only after that flush."""
     B, H, W, cin = x.shape
     cout = dy.shape[-1]
     ho, wo = conv_out_hw(H, W, ksize, stride)
@@ -317,8 +319,14 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
     nch = _abi.lib().sst_conv_wgrad_chunks2(B, H, W, cin, cout, ksize, stride, 1)
     slab = _f32(nch * ksize * ksize * cout * cin, like=x)
     e0 = _prof_begin()
+    pend = 0
+    if defer_reduce is not None and PROFILE is None and TRACE is None:
+        pend = _abi.lib().sst_conv_wgrad_pending_reduce(B, H, W, cin, cout, ksize, stride, int(in_scale is not None), int(in_act))
+        if pend:
+            assert dw_out.is_contiguous()
+            defer_reduce.append((slab, dw_out, pend, ksize * ksize, cout, cin, int(bool(accumulate))))
     args = (ptr(x), ptr(dy), ptr(slab), ptr(dw_out), ptr(in_scale), ptr(in_shift), ptr(in_slope), float(in_slope_const),
-            int(in_act), B, H, W, cin, cout, stride, ksize, int(accumulate), int(grp))
+            int(in_act), B, H, W, cin, cout, stride, ksize, int(bool(accumulate)) | (4 if pend else 0), int(grp))
     check(_abi.lib().sst_conv_wgrad_grp(*args, stream_ptr()), "sst_conv_wgrad")
     flops = 2.0 * B * ho * wo * cout * cin * ksize * ksize
     name = ""
@@ -329,6 +337,20 @@ def conv_wgrad(x, dy, dw_out, ksize=3, stride=1, in_scale=None, in_shift=None, i
     _trace(name, flops, lambda: _abi.lib().sst_conv_wgrad_grp(*args, stream_ptr()),
            x, dy, slab, dw_out, in_scale, in_shift, in_slope)
     return dw_out
+
+
+WGRAD_REDUCE_MULTI = os.environ.get("SST_WGRAD_REDUCE_MULTI", "1") != "0"    # slab reduces of a backward pass in one launch (0: dev A/B)
+
+
+def wgrad_reduce_flush(jobs):
+    """The slab reduces conv_wgrad(defer_reduce=jobs) left behind, in one launch per 24 jobs (sst_wgrad_reduce_multi); empties `jobs`."""
+    import ctypes
+    import struct
+    while jobs:
+        js, jobs[:] = jobs[:24], jobs[24:]
+        buf = b"".join(struct.pack("<QQiiiiii", slab.data_ptr(), dw.data_ptr(), nch, kk, cout, cin, acc, 0)
+                       for slab, dw, nch, kk, cout, cin, acc in js)
+        check(_abi.lib().sst_wgrad_reduce_multi(ctypes.c_char_p(buf), len(js), stream_ptr()), "sst_wgrad_reduce_multi")
 
 
 def bn_finalize(stats, cnt, gamma, beta, run_mean=None, run_var=None, eps=BN_EPS, momentum=BN_MOMENTUM, groups=1, out=None):

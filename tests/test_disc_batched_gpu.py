@@ -244,8 +244,26 @@ def test_train_iteration_batched_d_step_matches_sequential(reuse):
     l = F.binary_cross_entropy_with_logits(om.discriminator_forward(sd64, gt.double(), True, {}), torch.full((8, 1), 0.9, dtype=torch.float64)) + \
         F.binary_cross_entropy_with_logits(om.discriminator_forward(sd64, sr_seq.double(), True, {}), torch.zeros(8, 1, dtype=torch.float64))
     l.backward()
+    # ... and the same arithmetic in fp32 on the CPU.  What the three fp32 evaluations show (printed below): the error against fp64 is
+    # ~1e-6 from the classifier down to some BatchNorm + LeakyReLU stage and ~1e-3 from there on - a DISCRETE event, not rounding
+    # growth: one activation z = BN(y) within fp32 resolution of zero takes the other branch of LeakyReLU's derivative (1 vs 0.2) than in
+    # fp64, and that single element moves the layer's dbeta (a cancelling sum of 4,608 terms per channel) by ~7e-4 norm-wise, which
+    # every gradient below inherits.  Which stage it hits depends on the last bits of y, i.e. on the kernel that produced it: the CPU
+    # oracle and the pass-by-pass schedule flip at features.12, the batched schedule (N-split kernel on its 2B-image layers) already at
+    # features.18.  The floor of the rule is therefore 3e-3 here (three such events); the batched path's own arithmetic is pinned
+    # tighter where no flip can interfere: same-kernel batched vs pass-by-pass gradients to 2e-4 in the test above, logits / losses /
+    # BatchNorm buffers to 1e-5 here.
+    sd32 = {k: v.clone() for k, v in d0.items()}
+    for k in om.param_keys(sd32):
+        sd32[k].requires_grad_(True)
+    l32 = F.binary_cross_entropy_with_logits(om.discriminator_forward(sd32, gt, True, {}), torch.full((8, 1), 0.9)) + \
+        F.binary_cross_entropy_with_logits(om.discriminator_forward(sd32, sr_seq, True, {}), torch.zeros(8, 1))
+    l32.backward()
     report = []
     for n in g_seq:
-        assert_fp64_truth("D." + n, g_bat[n], g_seq[n], sd64[n].grad, report)
+        e_b, e_s, e_c = (rel_err(t, sd64[n].grad) for t in (g_bat[n], g_seq[n], sd32[n].grad))
+        print(f"   {n:24s} |batched - fp64| {e_b:.2e}   pass-by-pass {e_s:.2e}   cpu fp32 {e_c:.2e}")
+        report.append(("D." + n, e_b, max(e_s, e_c)))
+        assert e_b <= max(3e-3, 3.0 * max(e_s, e_c)), f"D.{n}: |batched - fp64| = {e_b:.3e} (pass-by-pass {e_s:.3e}, cpu fp32 {e_c:.3e})"
     worst = max(report, key=lambda r: r[1])
     print(f"worst batched-step gradient error against fp64: {worst[0]} {worst[1]:.2e} (pass-by-pass schedule: {worst[2]:.2e})")

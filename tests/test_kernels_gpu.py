@@ -159,6 +159,32 @@ def test_conv_dgrad_via_mode1_pack(ops, case):
     assert rel_err(nchw(dx.cpu()), x.grad) < TOL
 
 
+def test_conv_wgrad_deferred_slab_reduces(ops):
+    """conv_wgrad(defer_reduce=jobs) + ONE wgrad_reduce_flush for several layers of different shapes (sst_wgrad_reduce_multi) against the
+    per-layer reduce: bit-identical dW, with and without accumulation; shapes that write dW directly leave no job behind."""
+    g = torch.Generator().manual_seed(15)
+    cases = [(8, 48, 48, 64, 128, 3, 1), (8, 48, 48, 128, 128, 3, 2), (4, 24, 24, 64, 64, 3, 1), (2, 13, 9, 8, 8, 3, 1),
+             (2, 24, 24, 3, 64, 9, 1), (8, 12, 12, 512, 512, 3, 2), (4, 96, 96, 3, 64, 3, 1)]
+    jobs, pairs = [], []
+    for (B, H, W, Cin, Cout, k, s) in cases:
+        x = torch.randn(B, H, W, Cin, generator=g).cuda()
+        ho, wo = ops.conv_out_hw(H, W, k, s)
+        dy = torch.randn(B, ho, wo, Cout, generator=g).cuda()
+        base = torch.randn(Cout, Cin, k, k, generator=g).cuda()
+        for acc in (False, True):
+            ref = base.clone()
+            ops.conv_wgrad(x, dy, ref, k, s, accumulate=acc)
+            out = base.clone()
+            ops.conv_wgrad(x, dy, out, k, s, accumulate=acc, defer_reduce=jobs)
+            pairs.append((ref, out, (B, H, W, Cin, Cout, k, s, acc)))
+    assert 6 <= len(jobs) <= 24                       # some shapes write dW directly
+    ops.wgrad_reduce_flush(jobs)
+    assert not jobs
+    torch.cuda.synchronize()
+    for ref, out, c in pairs:
+        assert torch.equal(ref, out), c
+
+
 @pytest.mark.parametrize("case", [(2, 24, 24, 64, 64, 3, 1), (1, 13, 9, 8, 8, 3, 1), (2, 16, 16, 64, 256, 3, 1),
                                   (2, 24, 24, 64, 128, 3, 2), (2, 24, 24, 3, 64, 9, 1), (1, 32, 24, 64, 3, 9, 1),
                                   (1, 11, 7, 3, 64, 3, 1)])
