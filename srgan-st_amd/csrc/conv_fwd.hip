@@ -564,12 +564,17 @@ __global__ __launch_bounds__(CONV_NT) void conv3_c3in_mfma_kernel(const float* _
 // (dY) loaded straight from global memory as 16-B quads in MFMA layout (next tile's 12 quads in flight under the current tile's
 // MFMAs), the B operand (weights, 48 registers) read once from the ordinary mode-1 packed buffer.
 typedef float f32x4c __attribute__((ext_vector_type(4)));
+// nsp: a row is cut into nsp segments of Ws = W / nsp output columns, one wave each (nmt = tiles of a SEGMENT's Ws + 2 input columns):
+// at 96 px two 48-column segments are 8 M tiles per row instead of 7, but twice the waves (3 per SIMD instead of 1.5) cover the load
+// latency the one-tile-ahead prefetch leaves exposed (inside the step: 29.7 -> 28.8 us per launch at B = 16 - beside the other
+// branch's kernels; SST_TO3_NO_SPLIT=1 for the one-wave-per-row form).
 __global__ __launch_bounds__(CONV_NT) void conv3_to3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                            float* __restrict__ y, int B, int H, int W, int nmt) {
+                                                            float* __restrict__ y, int B, int H, int W, int nmt, int nsp) {
   extern __shared__ __attribute__((aligned(16))) float pl_all[];        // [wave][nmt * 16][12]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= B * H) return;                                // no workgroup barrier below
+  const int seg = blockIdx.x * 4 + wave;
+  if (seg >= B * H * nsp) return;                          // no workgroup barrier below
+  const int row = seg / nsp, Ws = W / nsp, xb = (seg - row * nsp) * Ws;
   const int b = row / H, oy = row - b * H;
   const int lm = lane & 15, lg = lane >> 4;
   float* const pl = pl_all + (size_t)wave * nmt * 16 * 12;
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(CONV_NT) void conv3_to3_kernel(const float* __restr
         }
   }
   auto load_tile = [&](int mt, f32x4c (&a)[3][4]) {
-    const int xp = mt * 16 + lm - 1;
+    const int xp = xb + mt * 16 + lm - 1;
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty) {
       const int iy = oy - 1 + ty;
@@ -624,8 +629,8 @@ __global__ __launch_bounds__(CONV_NT) void conv3_to3_kernel(const float* __restr
       for (int q = 0; q < 4; ++q) ac[ty][q] = an[ty][q];
   }
   // horizontal fold (LDS ops of a wave complete in order): dx[x][ci] = sum_tx P[x + tx][(tx, ci)]  (local x' index = x' + 1)
-  float* const out = y + ((size_t)b * H + oy) * W * 3;
-  for (int i = lane; i < 3 * W; i += 64) {
+  float* const out = y + (((size_t)b * H + oy) * W + xb) * 3;
+  for (int i = lane; i < 3 * Ws; i += 64) {
     const int xo = i / 3, ci = i - xo * 3;
     out[i] = (pl[xo * 12 + ci] + pl[(xo + 1) * 12 + 3 + ci]) + pl[(xo + 2) * 12 + 6 + ci];
   }
@@ -869,10 +874,11 @@ static int conv_fwd_impl(const float* x, const float* wp, float* y, float* y_pre
   a.dbg = dbg_bits & 15;
   if (ksize == 3 && stride == 1 && Cin == 64 && Cout == 3 && out_mode == OUT_NHWC && !bias && !in_scale && in_act == ACT_NONE && !residual &&
       !stats && !y_pre && !epi_partial && !in2 && dbg_bits == 0 && !sst_env("SST_NO_TO3")) {
-    const int nmt = (W + 2 + 15) / 16;
+    const int nsp = (W % 32 == 0 && W >= 64 && !sst_env("SST_TO3_NO_SPLIT")) ? 2 : 1;
+    const int nmt = (W / nsp + 2 + 15) / 16;
     const size_t lds = (size_t)4 * nmt * 16 * 12 * sizeof(float);
     if (lds <= 60 * 1024) {
-      conv3_to3_kernel<<<(unsigned)((B * H + 3) / 4), CONV_NT, lds, st>>>(x, wp, y, B, H, W, nmt);
+      conv3_to3_kernel<<<(unsigned)((B * H * nsp + 3) / 4), CONV_NT, lds, st>>>(x, wp, y, B, H, W, nmt, nsp);
       SST_LAUNCH_CHECK("conv3_to3_kernel");
       return SST_OK;
     }

@@ -476,38 +476,47 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_mfma_kernel(const float* _
   // a wave accumulates C3M_TPW row segments (tiles blockIdx.x * 4 * C3M_TPW + wave + 4 i) before the workgroup writes its partial:
   // one 64 x 27 partial per 4 * C3M_TPW tiles - the slab and its reduce (15.9 MB / 43 us with one partial per 4 tiles at B = 32)
   // shrink by C3M_TPW
-  for (int it = 0; it < C3M_TPW; ++it) {
-  const int t = (blockIdx.x * C3M_TPW + it) * 4 + wave;
-  const bool live = t < ntiles;
-  const int b = t / (H * tpr), rem = t - b * (H * tpr);
-  const int y = rem / tpr, x0 = (rem - y * tpr) << 5;
-  // dY in MFMA layout: K step ks, half h -> channel 32h + li of pixel x0 + 2ks + lh
-  float av[16][2];
-  {
-    const float* dp = dy + (((size_t)b * H + y) * W + x0 + lh) * Cout + li;
+  // Software pipeline over the wave's tiles: the dY fragments (32 registers) and the patch values (5) of tile it + 1 are loaded before the
+  // 32 MFMAs of tile it are issued - with 2-3 waves per SIMD and load -> wait -> multiply in sequence the launch ran at 1.9 TB/s
+  // (42.4 -> 36.6 us inside the step at B = 32).
+  float av[2][16][2], xv[2][5];
+  auto issue = [&](int it, float (&a_)[16][2], float (&x_)[5]) {
+    const int t = (blockIdx.x * C3M_TPW + it) * 4 + wave;
+    const bool live = it < C3M_TPW && t < ntiles;
+    const int b = t / (H * tpr), rem = t - b * (H * tpr);
+    const int y = rem / tpr, x0 = (rem - y * tpr) << 5;
+    // dY in MFMA layout: K step ks, half h -> channel 32h + li of pixel x0 + 2ks + lh
+    const float* dp = dy + (live ? (((size_t)b * H + y) * W + x0 + lh) * Cout + li : 0);
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      av[ks][0] = live ? dp[(size_t)(2 * ks) * Cout] : 0.f;
-      av[ks][1] = live ? dp[(size_t)(2 * ks) * Cout + 32] : 0.f;
+      a_[ks][0] = live ? dp[(size_t)(2 * ks) * Cout] : 0.f;
+      a_[ks][1] = live ? dp[(size_t)(2 * ks) * Cout + 32] : 0.f;
     }
-  }
-  // X patch rows y-1 .. y+1, columns x0-1 .. x0+32 (as floats: (x0-1)*3 .. +102), zero outside the image; then the zero region
+    // X patch rows y-1 .. y+1, columns x0-1 .. x0+32 (as floats: (x0-1)*3 .. +102), zero outside the image
 #pragma unroll
-  for (int u = 0; u < 5; ++u) {
-    const int i = lane + 64 * u;
-    if (i < 306) {
+    for (int u = 0; u < 5; ++u) {
+      const int i = lane + 64 * u;
       const int r = i / 102, c = i - r * 102;
       const int iy = y - 1 + r, fx = (x0 - 1) * 3 + c;
-      const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)fx < (unsigned)(W * 3);
-      ps[r * C3M_ROW + c] = ok ? x[((size_t)b * H + iy) * W * 3 + fx] : 0.f;
+      const bool ok = live && i < 306 && (unsigned)iy < (unsigned)H && (unsigned)fx < (unsigned)(W * 3);
+      x_[u] = ok ? x[((size_t)b * H + iy) * W * 3 + fx] : 0.f;
     }
-  }
+  };
+  issue(0, av[0], xv[0]);
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const float bv = bl[6 * ks];                          // LDS ops of a wave complete in order: the stores above have landed
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][0], bv, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][1], bv, acc[1], 0, 0, 0);
-  }
+  for (int it = 0; it < C3M_TPW; ++it) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i = lane + 64 * u;
+      if (i < 306) ps[(i / 102) * C3M_ROW + i % 102] = xv[it & 1][u];      // (the previous tile's LDS reads were issued before: in order)
+    }
+    if (it + 1 < C3M_TPW) issue(it + 1, av[(it + 1) & 1], xv[(it + 1) & 1]);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float bv = bl[6 * ks];                        // LDS ops of a wave complete in order: the stores above have landed
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[it & 1][ks][0], bv, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[it & 1][ks][1], bv, acc[1], 0, 0, 0);
+    }
   }   // tiles of this wave
   // 4 waves -> one 64 x 27 partial (fixed order), slab [chunk][tap][Cout][3]
   float* const out = slab + (size_t)blockIdx.x * 9 * Cout * 3;
@@ -525,33 +534,48 @@ __global__ __launch_bounds__(CONV_NT) void wgrad_k3c3_mfma_kernel(const float* _
     }
   }
 }
-// dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci] for the kernel above (64 x 27 outputs, > 1000 chunks): one workgroup per 64
-// outputs, 16 chunk groups of 64 lanes (coalesced 256-B rows, 8 loads in flight per thread), combined in fixed order through LDS.
+// dW[co][ci][tap] (+)= sum_chunk slab[chunk][tap][co][ci] for the kernel above (64 x 27 = 1,728 outputs, 288-576 chunks): a workgroup
+// takes 16 outputs x 64 chunk groups (64-B runs per chunk row; 108 workgroups instead of the 27 of the 64-output form, whose 16 groups
+// walked 36 dependent loads each: 26.6 us for 4 MB at B = 32 inside the step, 22.2 now), <= 9 loads per thread in two batches, combined in
+// fixed order through LDS.
+constexpr int C3R_OUT = 16, C3R_GRP = 1024 / C3R_OUT;
 __global__ __launch_bounds__(1024) void c3m_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunk,
                                                           int accumulate) {
-  __shared__ float part[16][64];
+  __shared__ float part[C3R_GRP][C3R_OUT + 1];
   constexpr int TOTAL = 9 * 64 * 3;
-  const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + o;
+  const int o = threadIdx.x & (C3R_OUT - 1), gq = threadIdx.x / C3R_OUT;
+  const int i = blockIdx.x * C3R_OUT + o;
   float t = 0.f;
   int c = gq;
-  for (; c + 7 * 16 < nchunk; c += 8 * 16) {
+  for (; c + 7 * C3R_GRP < nchunk; c += 8 * C3R_GRP) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(c + 16 * u) * TOTAL + i];
+    for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(c + C3R_GRP * u) * TOTAL + i];
 #pragma unroll
     for (int u = 0; u < 8; ++u) t += v[u];
   }
-  for (; c < nchunk; c += 16) t += slab[(size_t)c * TOTAL + i];
+  {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = c + C3R_GRP * u < nchunk ? slab[(size_t)(c + C3R_GRP * u) * TOTAL + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
   part[gq][o] = t;
   __syncthreads();
-  if (gq == 0) {
-    t = part[0][o];
+  if (threadIdx.x < 64) {                                  // 4 lanes per output, 16 groups each, then two shuffles: fixed order
+    const int oo = threadIdx.x & (C3R_OUT - 1), q = threadIdx.x / C3R_OUT;
+    t = 0.f;
 #pragma unroll
-    for (int k = 1; k < 16; ++k) t += part[k][o];
-    const int tap = i / 192, oc = i - tap * 192;         // slab order [tap][co][ci] -> dW[co][ci][tap]
-    float* d = dw + (size_t)oc * 9 + tap;
-    *d = accumulate ? *d + t : t;
+    for (int k = 0; k < C3R_GRP / 4; ++k) t += part[q * (C3R_GRP / 4) + k][oo];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if (q == 0) {
+      const int ii = blockIdx.x * C3R_OUT + oo;
+      const int tap = ii / 192, oc = ii - tap * 192;      // slab order [tap][co][ci] -> dW[co][ci][tap]
+      float* d = dw + (size_t)oc * 9 + tap;
+      *d = accumulate ? *d + t : t;
+    }
   }
 }
 inline bool k3c3_mfma_applies(int W, int Cout) { return (W & 31) == 0 && Cout == 64 && !sst_env("SST_WGRAD_NO_K3C3_MFMA"); }
@@ -1176,7 +1200,7 @@ SST_API int sst_conv_wgrad_grp(const float* x, const float* dy, float* slab, flo
     nchunk = k3c3_mfma_chunks(B, H, W);
     wgrad_k3c3_mfma_kernel<<<nchunk, CONV_NT, 0, sst_stream(stream)>>>(x, dy, slab, B, H, W, B * H * (W >> 5));
     SST_LAUNCH_CHECK("wgrad_k3c3_mfma_kernel");
-    c3m_reduce_kernel<<<27, 1024, 0, sst_stream(stream)>>>(slab, dw, nchunk, accumulate);
+    c3m_reduce_kernel<<<9 * 64 * 3 / C3R_OUT, 1024, 0, sst_stream(stream)>>>(slab, dw, nchunk, accumulate);
     SST_LAUNCH_CHECK("c3m_reduce_kernel");
     return SST_OK;
   } else if (k3c3_applies(Cin, ksize, stride, in_scale, in_act) && !sst_env("SST_WGRAD_NO_K3C3")) {
