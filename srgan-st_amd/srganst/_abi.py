@@ -159,6 +159,10 @@ def lib() -> ctypes.CDLL:
             raise HipPathError(
                 f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C srgan-st_amd/csrc).  There is no CPU fallback for the HIP path.")
+        # PyTorch-ROCm first: it brings its own libamdhip64, and the library must bind to THAT runtime (the one that owns the tensors'
+        # device context and streams).  Loaded before torch, libsrganst.so pulls in the system ROCm runtime instead and its first
+        # launch fails with "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process).
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)           # AttributeError if the .so is stale: also loud
