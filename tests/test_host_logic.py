@@ -184,3 +184,34 @@ def test_bench_launcher_propagates_a_failed_rank():
     non-zero and print no JSON line."""
     p = _run_bench({}, "--gpus", "2", "--steps", "1", "--no-roofline", "--no-cpu-baseline", "--no-secondary")
     assert p.returncode != 0 and "exited with" in p.stderr and not p.stdout.strip()
+
+
+def test_kernel_selection_plans_of_the_library():
+    """Host-side plans of libsrganst.so (no GPU call): which conv form takes a shape, and how many slab chunks a weight gradient leaves
+    for the one-launch reduce.  The numbers are the step's own layers (model.py:30-59 at B = 16 / 32, 96-px crops)."""
+    from srganst import _abi
+    L = _abi.lib()
+    NHWC, SHUFFLE = 0, 1
+    # N-split kernel: Cout % 128 == 0 and >= 1,024 (tile, 128-channel) units
+    assert L.sst_conv_ns_supported(32, 48, 48, 64, 128, 3, 1, NHWC) == 8          # 2,304 units
+    assert L.sst_conv_ns_supported(16, 48, 48, 64, 128, 3, 1, NHWC) == 8          # 1,152
+    assert L.sst_conv_ns_supported(32, 24, 24, 128, 256, 3, 1, NHWC) == 8         # 576 tiles x 2 groups
+    assert L.sst_conv_ns_supported(16, 24, 24, 128, 256, 3, 1, NHWC) == 0         # 576 units: K-split kernel
+    assert L.sst_conv_ns_supported(32, 12, 12, 256, 512, 3, 1, NHWC) == 0
+    assert L.sst_conv_ns_supported(32, 96, 96, 64, 64, 3, 2, NHWC) == 0           # 64 output channels
+    assert L.sst_conv_ns_supported(32, 48, 48, 128, 128, 3, 2, NHWC) == 0          # 576 units
+    assert L.sst_conv_ns_supported(64, 48, 48, 128, 128, 3, 2, NHWC) == 8
+    # ... every shape it takes is one the K-split kernel takes too (same tiling, same statistics rows)
+    for shp in [(32, 48, 48, 64, 128, 3, 1), (64, 48, 48, 128, 128, 3, 2), (32, 24, 24, 128, 256, 3, 1)]:
+        assert L.sst_conv_pipe_supported(*shp) == L.sst_conv_ns_supported(*shp, NHWC)
+    # PixelShuffle store (the generator's up-sampling convs, model.py:157-161): 512 units suffice, no other store mode
+    assert L.sst_conv_ns_supported(16, 24, 24, 64, 256, 3, 1, SHUFFLE) == 8
+    assert L.sst_conv_ns_supported(16, 48, 48, 64, 256, 3, 1, SHUFFLE) == 8
+    assert L.sst_conv_ns_supported(2, 24, 24, 64, 256, 3, 1, SHUFFLE) == 0
+    assert L.sst_conv_ns_supported(16, 48, 48, 64, 256, 3, 1, 2) == 0
+    # slab chunks left for sst_wgrad_reduce_multi: the all-taps tile kernel's chunk count; 0 where the launch writes dW itself
+    for shp in [(32, 48, 48, 64, 128, 3, 1), (32, 96, 96, 64, 64, 3, 2), (32, 12, 12, 256, 512, 3, 1)]:
+        n = L.sst_conv_wgrad_pending_reduce(*shp, 1, 1)
+        assert n == L.sst_conv_wgrad_chunks2(*shp, 1) and n >= 1
+    assert L.sst_conv_wgrad_pending_reduce(32, 96, 96, 3, 64, 3, 1, 0, 0) == 0    # first layer: MFMA kernel with its own reduce
+    assert L.sst_conv_wgrad_pending_reduce(2, 13, 9, 3, 64, 3, 1, 0, 0) == 2 * 2  # 3-channel VALU kernel: one chunk per 8-row band
