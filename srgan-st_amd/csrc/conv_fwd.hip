@@ -695,6 +695,11 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
     for (int u = 0; u < 4; ++u) {
       const long long idx = base + u * 256 + threadIdx.x;
       if (idx >= jb.total) break;
+      // 5 / 6: the two one-line launches that used to stand next to a network's pack at the head of its forward ride along as jobs -
+      // 5 clears `total` 32-bit words at wp (the trunk's fp64 statistics accumulators), 6 adds Cout to `total` int64 words at wp (the
+      // BatchNorm layers' num_batches_tracked, one flat tensor per network)
+      if (jb.mode == 5) { jb.wp[idx] = 0.f; continue; }
+      if (jb.mode == 6) { reinterpret_cast<long long*>(jb.wp)[idx] += jb.Cout; continue; }
       jb.wp[idx] = jb.mode == 4 ? pack_to3_value(jb.w, idx, jb.Cin) : pack_c3_value(jb.w, idx, jb.Cout, jb.Cin, jb.mode - 2);
     }
     return;
@@ -811,7 +816,8 @@ SST_API int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksiz
 }
 
 // jobs: device array of {w, wp, Cout, Cin, KK, mode, total, block_begin} (8 x 8 bytes each, see srganst/ops.py);
-// mode 0 / 1: forward / data-gradient layout of a k x k conv; 2 / 3: sst_conv9_c3_pack mode 0 / 1; 4: sst_conv9_to3_pack
+// mode 0 / 1: forward / data-gradient layout of a k x k conv; 2 / 3: sst_conv9_c3_pack mode 0 / 1; 4: sst_conv9_to3_pack;
+// 5: clear `total` 32-bit words at wp (w unused); 6: add Cout to `total` int64 words at wp (w unused)
 SST_API int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, void* stream) {
   SST_REQUIRE(jobs && njobs > 0 && total_blocks > 0, "sst_conv_pack_multi: bad argument");
   static_assert(sizeof(PackJob) == 48, "PackJob layout");

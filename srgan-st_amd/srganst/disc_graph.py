@@ -17,7 +17,7 @@ LRELU = 0.2
 PLAN = [(0, None, 1), (2, 3, 2), (5, 6, 1), (8, 9, 2), (11, 12, 1), (14, 15, 2), (17, 18, 1), (20, 21, 2)]
 
 
-def _packs(module, p, with_dgrad):
+def _packs(module, p, with_dgrad, counter_add=0):
     """(forward packs by name, stride-1 data-gradient packs by name, stride-2 data-gradient packs by name) - the last two None
     without with_dgrad.  One multi-tensor launch + one launch per stride-2 layer.
 
@@ -25,7 +25,9 @@ def _packs(module, p, with_dgrad):
     (train.py:125-161: D(sr) in the generator step, D(gt) and D(sr) in its own step).  An owner that controls those updates
     (engine.TrainEngine) sets module._packs_managed and clears module._packs_fresh after every optimizer step; while the flag
     is set (and no parameter was rebound or modified through torch, see _version) the packed buffers are handed out again
-    without a launch.  Without an owner every call packs, as before."""
+    without a launch.  Without an owner every call packs, as before.
+    counter_add > 0 (the owner's call at the head of an iteration, which always packs): the BatchNorm batch counters' add for the
+    iteration's passes rides in the pack launch."""
     cache = module.__dict__.setdefault("_hip_cache", {})
     names = [f"features.{ci}.weight" for ci, _, s in PLAN]
     n1 = [f"features.{ci}.weight" for ci, _, s in PLAN if s == 1]
@@ -34,10 +36,12 @@ def _packs(module, p, with_dgrad):
     st = cache.get("pack_state")
     if (module.__dict__.get("_packs_managed") and module.__dict__.get("_packs_fresh") and st is not None and st["sig"] == sig
             and (st["wd"] is not None or not with_dgrad)):
+        assert not counter_add, "the packs are fresh: nothing to ride along with"
         return st["wp"], st["wd"], st["ws2"]
     ws = [p[n] for n in names] + ([p[n] for n in n1] if with_dgrad else [])
     modes = [ops.PACK_FWD] * len(names) + ([ops.PACK_DGRAD] * len(n1) if with_dgrad else [])
-    out = ops.packed_weights(cache, ("pack", bool(with_dgrad)), ws, modes)
+    extras = (("add", ops.flatten_bn_counters(module), int(counter_add)),) if counter_add else ()
+    out = ops.packed_weights(cache, ("pack", bool(with_dgrad), int(counter_add)), ws, modes, extras)
     wp = dict(zip(names, out[:len(names)]))
     wd = ws2 = None
     if with_dgrad:

@@ -659,20 +659,24 @@ class TrainEngine:
         adv_d = "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS
         # the batch counters of D's BatchNorms move by one per pass (run or replayed): ONE add per iteration instead of three
         self.D.__dict__["_counters_external"] = True
-        ops.flatten_bn_counters(self.D).add_(3 if adv_d else 2)
+        n_pass = 3 if adv_d else 2
+        adv = adv_d
+        ride = bool(adv and cfg.KERNEL.EARLY_D_PACK)       # ... and that add rides in the early pack launch below when there is one
+        if not ride:
+            ops.flatten_bn_counters(self.D).add_(n_pass)
         ops.debug_stamp(0)
         main = torch.cuda.current_stream()
         if self._side_d is None:
             self._side_d = torch.cuda.Stream()
         early_gt = None
-        adv = "Adversarial" in cfg.MODEL.G_LOSS.CRITERIONS
         if adv and (cfg.KERNEL.EARLY_D_PACK or cfg.KERNEL.EARLY_D_GT):
             # D's weights are packed (one multi-tensor launch + one per stride-2 layer, 67 us) for all passes of the iteration on the
             # side stream, beside the generator's forward, instead of in front of D(sr) on the critical path
             names = [n for n, _ in self.D.named_parameters()]
             self._side_d.wait_stream(main)
             with torch.cuda.stream(self._side_d):
-                disc_graph._packs(self.D, dict(zip(names, [t.detach() for t in self.D.parameters()])), True)
+                disc_graph._packs(self.D, dict(zip(names, [t.detach() for t in self.D.parameters()])), True,
+                                  counter_add=n_pass if ride else 0)
                 if cfg.KERNEL.EARLY_D_GT:            # D(gt)'s forward beside the generator's forward as well (measured slower, off)
                     early_gt = self._d_gt_fwd()
         sr = self.G(self.lr)

@@ -48,10 +48,10 @@ def _conv_names(module, fast9):
     return names
 
 
-def _packs(module, p, with_dgrad):
+def _packs(module, p, with_dgrad, extras=()):
     """All packed weights of the generator from ONE multi-tensor launch: (forward packs by name, data-gradient packs by name or
     None, packs of the (kx, 3ch)-folded 9x9 kernels {"conv1", "conv3", "conv3.dgrad"}).  The data-gradient packs are made by
-    the training forward and handed to backward() (the weights do not change in between)."""
+    the training forward and handed to backward() (the weights do not change in between).  extras: ops.PackPlan's riders."""
     cache = module.__dict__.setdefault("_hip_cache", {})
     fast9 = _fast9(module, p)
     names = _conv_names(module, fast9)
@@ -67,7 +67,7 @@ def _packs(module, p, with_dgrad):
             nine.append(("conv3.dgrad", "conv3.weight", ops.PACK_C3_DGRAD))
         ws += [p[n] for _, n, _ in nine]
         modes += [m for _, _, m in nine]
-    out = ops.packed_weights(cache, ("pack", bool(with_dgrad)), ws, modes)
+    out = ops.packed_weights(cache, ("pack", bool(with_dgrad), tuple(e[0] for e in extras)), ws, modes, extras)
     k = len(names)
     wp = dict(zip(names, out[:k]))
     wd = dict(zip(names, out[k:2 * k])) if with_dgrad else None
@@ -75,13 +75,15 @@ def _packs(module, p, with_dgrad):
     return wp, wd, w9
 
 
-def _bn_accumulators(module, nblocks, C, device, zero):
+def _bn_accumulators(module, nblocks, C, device, zero, whole=False):
     """The fp64 statistics accumulators of the accumulator mode, forward [2*nblocks+1][NREP][C][2] and backward
-    [2*nblocks][NREP][C][4], as views of ONE buffer so that one fill at the start of the forward clears both."""
+    [2*nblocks][NREP][C][4], as views of ONE buffer so that one fill at the start of the forward clears both (whole: that buffer)."""
     nf, nbk = (2 * nblocks + 1) * ops.ACC_NREP * C * 2, 2 * nblocks * ops.ACC_NREP * C * 4
     buf = module.__dict__.get("_bn_acc_buf")
     if buf is None or buf.numel() != nf + nbk or buf.device != device:
         buf = module.__dict__["_bn_acc_buf"] = torch.zeros(nf + nbk, device=device, dtype=torch.float64)
+    if whole:
+        return buf
     if zero == "all":
         buf.zero_()
     elif zero == "bwd":
@@ -94,10 +96,18 @@ def forward(module, x, params, need_grad):
     training = module.training
     sv = {}                                       # saved for backward
     C = p["conv1.0.weight"].shape[0]
-    wp, sv["wd"], w9 = _packs(module, p, need_grad)
+    # the batch counters' add and the clearing of the statistics accumulators (two one-line launches at the head of the serial chain)
+    # ride in the pack launch
+    B_, H_, W_ = x.shape[0], x.shape[2], x.shape[3]
+    use_acc = bool(training and len(module.trunk) and ops.conv_acc_supported(B_, H_, W_, C, C))
+    extras = []
+    counters = ops.flatten_bn_counters(module) if training else None
+    if counters is not None:
+        extras.append(("add", counters, 1))
+    if use_acc:
+        extras.append(("zero", _bn_accumulators(module, len(module.trunk), C, x.device, zero=None, whole=True)))
+    wp, sv["wd"], w9 = _packs(module, p, need_grad, tuple(extras))
     sv["w9"] = w9
-    if training:
-        ops.flatten_bn_counters(module).add_(1)
     x3 = ops.transpose(x.contiguous(), to_nchw=False)                                  # [B,h,w,3]
     fast9 = _fast9(module, p)
     if fast9:
@@ -117,13 +127,12 @@ def forward(module, x, params, need_grad):
 
     h = z1
     blocks = []
-    B_, H_, W_, _ = z1.shape
     n_px = float(B_ * H_ * W_)
-    if training and len(module.trunk) and ops.conv_acc_supported(B_, H_, W_, C, C):
+    if use_acc:
         # ---- accumulator mode: no BatchNorm finalize launches - each conv adds its output statistics into fp64 accumulators and
         # the NEXT conv derives the affine of its input from them in its prologue (csrc/conv_epilogue.h: BandAcc)
         nbn = 2 * len(module.trunk) + 1
-        acc, _ = _bn_accumulators(module, len(module.trunk), C, z1.device, zero="all")
+        acc, _ = _bn_accumulators(module, len(module.trunk), C, z1.device, zero=None)       # cleared by the pack launch above
         sv["acc_token"] = module.__dict__["_bn_acc_token"] = object()      # backward: its accumulators are still clear
 
         def stat_tensors():

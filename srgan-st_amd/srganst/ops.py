@@ -690,9 +690,9 @@ class PackPlan:
     """All conv weights of a network packed by ONE kernel launch (sst_conv_pack_multi).  The job table and the
     packed buffers are persistent, so the launch is graph-capturable; rebuild when a parameter moves."""
 
-    def __init__(self, weights, modes):
+    def __init__(self, weights, modes, extras=()):
         dev = weights[0].device
-        self.ptrs = tuple(w.data_ptr() for w in weights)
+        self.ptrs = tuple(w.data_ptr() for w in weights) + self._extras_sig(extras)
         self.out, rows, blk = [], [], 0
         for w, m in zip(weights, modes):
             cout, cin, k, _ = w.shape
@@ -707,22 +707,41 @@ class PackPlan:
             self.out.append(wp)
             rows.append([w.data_ptr(), wp.data_ptr(), cout | (cin << 32), (k * k) | (int(m) << 32), n, blk])
             blk += (n + 1023) // 1024
+        # extras ride along in the same launch (csrc/conv_fwd.hip: pack_multi_kernel modes 5 / 6): ("zero", tensor) clears it,
+        # ("add", int64 tensor, k) adds k to every element - the statistics accumulators and BatchNorm batch counters of a forward
+        for e in extras:
+            if e[0] == "zero":
+                t = e[1]
+                assert t.is_contiguous() and t.element_size() % 4 == 0
+                n = t.numel() * (t.element_size() // 4)
+                rows.append([0, t.data_ptr(), 0, 5 << 32, n, blk])
+            else:
+                t, k = e[1], int(e[2])
+                assert e[0] == "add" and t.dtype == torch.int64 and t.is_contiguous() and 0 <= k < 2 ** 31
+                n = t.numel()
+                rows.append([0, t.data_ptr(), k, 6 << 32, n, blk])
+            blk += (n + 1023) // 1024
+        self.njobs = len(rows)
         self.blocks = blk
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
 
-    def matches(self, weights):
-        return self.ptrs == tuple(w.data_ptr() for w in weights)
+    @staticmethod
+    def _extras_sig(extras):
+        return tuple((e[0], e[1].data_ptr(), e[1].numel(), int(e[2]) if len(e) > 2 else 0) for e in extras)
+
+    def matches(self, weights, extras=()):
+        return self.ptrs == tuple(w.data_ptr() for w in weights) + self._extras_sig(extras)
 
     def run(self):
-        check(_abi.lib().sst_conv_pack_multi(ptr(self.table), len(self.out), self.blocks, stream_ptr()), "sst_conv_pack_multi")
+        check(_abi.lib().sst_conv_pack_multi(ptr(self.table), self.njobs, self.blocks, stream_ptr()), "sst_conv_pack_multi")
         return self.out
 
 
-def packed_weights(cache: dict, key, weights, modes):
-    """cache: a dict living on the module.  Returns the list of packed tensors (freshly re-packed)."""
+def packed_weights(cache: dict, key, weights, modes, extras=()):
+    """cache: a dict living on the module.  Returns the list of packed tensors (freshly re-packed); `extras`: see PackPlan."""
     plan = cache.get(key)
-    if plan is None or not plan.matches(weights):
-        plan = PackPlan(weights, modes)
+    if plan is None or not plan.matches(weights, extras):
+        plan = PackPlan(weights, modes, extras)
         cache[key] = plan
     return plan.run()
 
