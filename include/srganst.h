@@ -80,6 +80,10 @@ long sst_debug_band_launches(void);       /* test hook: launches of the band con
 long sst_debug_wgrad_band_launches(void); /* test hook: launches of the all-taps weight-gradient kernel so far */
 /* measurement hook (tools/mfma_peak.py): `blocks` workgroups x 4 waves x iters x 4 v_mfma_f32_32x32x2_f32, no memory traffic */
 int sst_debug_mfma_peak(float* out, int blocks, int iters, void* stream);
+/* measurement hook (tools/bf16x3_probe.py): the split-operand bf16 MFMA form proposed in DESIGN.md section 8 - mode 0: one 32 x 32 x K
+ * product by the fp32 MFMA (C32) and by six bf16 MFMAs per 16 k (C3) for an accuracy comparison on the host; mode 1: rate of the
+ * six-MFMA group in a register-only loop (C32 = scratch, K = iterations, blocks workgroups).  Not used by the product path. */
+int sst_debug_bf16x3(const float* A, const float* B, float* C32, float* C3, int K, int mode, int blocks, void* stream);
 /* measurement hook (tools/stamp_step.py): out[slot] = the device's 100 MHz wall clock at the point of the stream / captured graph */
 int sst_debug_stamp(unsigned long long* out, int slot, void* stream);
 int sst_conv_fwd(const float* x, const float* wp, float* y, float* y_pre, const float* bias,

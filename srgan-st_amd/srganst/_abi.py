@@ -37,6 +37,7 @@ SIGNATURES = {
     "sst_debug_band_launches": (ctypes.c_long, []),
     "sst_debug_wgrad_band_launches": (ctypes.c_long, []),
     "sst_debug_mfma_peak": (c_int, [P, c_int, c_int, P]),
+    "sst_debug_bf16x3": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "sst_debug_stamp": (c_int, [P, c_int, P]),
     "sst_conv_mtiles": (c_int, [c_int, c_int, c_int]),
     "sst_conv_stat_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
