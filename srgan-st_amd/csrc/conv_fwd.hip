@@ -682,11 +682,17 @@ struct PackJob {
   long long total;
   long long block_begin;    // first workgroup of this job (each workgroup packs 1024 floats)
 };
+// The job of a workgroup's block is found by binary search over the jobs' first blocks - in an LDS copy of that column (one coalesced
+// load per workgroup): searched in global memory it is 6-7 DEPENDENT loads in front of every block's gathers.
+constexpr int PM_MAXJOBS = 512;
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  __shared__ long long s_begin[PM_MAXJOBS];
+  for (int j = threadIdx.x; j < njobs; j += 256) s_begin[j] = jobs[j].block_begin;
+  __syncthreads();
   int lo = 0, hi = njobs - 1;                       // last job with block_begin <= blockIdx.x
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].block_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (s_begin[mid] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const PackJob jb = jobs[lo];
   if (jb.mode >= 2) {                               // 9x9 convs with a 3-channel side: 2 / 3 = c3 mode 0 / 1, 4 = to3
@@ -706,29 +712,109 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
   }
   const int O = jb.mode ? jb.Cin : jb.Cout, I = jb.mode ? jb.Cout : jb.Cin;
   const int ncb = (I + 63) / 64;
-  const long long base = ((long long)blockIdx.x - jb.block_begin) * 1024;
-  const long long bbase = packed_floats_base(O, I, jb.KK);
+  const unsigned wl = (unsigned)((long long)blockIdx.x - jb.block_begin);          // this workgroup's 1,024-float block of the job
+  const unsigned bbase = (unsigned)packed_floats_base(O, I, jb.KK), total = (unsigned)jb.total;     // (< 2^31: checked by the caller)
+  if (jb.KK == 9) {
+    // 3x3 weights: the packed element (o, i, tap) comes from w[o][i][tap] (mode 1: w[i][o][8 - tap]) - gathered element by element
+    // that is one 64-B sector per 4 bytes (the generator's 5 M packed floats pulled 320 MB through L2: 33-40 us at the head of the
+    // iteration).  Here the workgroups of a (32 o x 32 i) block's NINE taps are folded into the first of them: it reads the block's
+    // 32 rows of 32 x 9 contiguous floats once (coalesced) into LDS and writes all nine 1,024-float packed blocks; the other eight
+    // exit.  Same for the band section (16 o x 64 i x 9 taps per workgroup).
+    __shared__ float tile[64 * 145];                      // [32 rows][288 + 1] / band section: [16][576 + 1] or [64][144 + 1]
+    const unsigned nhalf = (unsigned)((O + 31) / 32) * ncb * 9 * 2;                // half-slab blocks of the first section
+    const bool band = wl >= nhalf + PACK_PAD / 1024;
+    if (!band && wl >= nhalf) {                           // the pad
+#pragma unroll
+      for (int u = 0; u < 4; ++u) jb.wp[wl * 1024 + u * 256 + threadIdx.x] = 0.f;
+      return;
+    }
+    if (!band) {
+      const unsigned ngrp = nhalf / 9;
+      if (wl >= ngrp) return;
+      const int h = wl & 1, cbk = (wl >> 1) % (unsigned)ncb, of = (wl >> 1) / (unsigned)ncb;
+      const int o0 = of * 32, i0 = cbk * 64 + h * 32;
+      // rows: mode 0 -> o (columns i_local * 9 + tap), mode 1 -> i (columns o_local * 9 + (8 - tap))
+      float v[36];                                        // 32 x 288 / 256: every load issued before the first LDS store
+#pragma unroll
+      for (int k = 0; k < 36; ++k) {
+        const int e = k * 256 + threadIdx.x;
+        const int r = e / 288, c = e - r * 288, q = c / 9;
+        v[k] = 0.f;
+        if (jb.mode == 0) {
+          if (o0 + r < O && i0 + q < I) v[k] = jb.w[((size_t)(o0 + r) * jb.Cin + i0) * 9 + c];
+        } else {
+          if (i0 + r < I && o0 + q < O) v[k] = jb.w[((size_t)(i0 + r) * jb.Cin + o0) * 9 + c];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 36; ++k) {
+        const int e = k * 256 + threadIdx.x;
+        const int r = e / 288, c = e - r * 288;
+        tile[r * 289 + c] = v[k];
+      }
+      __syncthreads();
+      for (int tap = 0; tap < 9; ++tap) {
+        float* dst = jb.wp + ((size_t)((of * ncb + cbk) * 9 + tap) * 2 + h) * 1024;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int x = u * 256 + threadIdx.x;
+          const int j = x & 3, l = (x >> 2) & 63, ks = x >> 8;
+          const int ol = l & 31, il = ks * 8 + (l >> 5) * 4 + j;
+          dst[x] = jb.mode == 0 ? tile[ol * 289 + il * 9 + tap] : tile[il * 289 + ol * 9 + (8 - tap)];
+        }
+      }
+      return;
+    }
+    // band section [o / 16][tap][i / 16][64 lanes][4] (conv_common.h: band_index; I = 64)
+    const unsigned wb = wl - nhalf - PACK_PAD / 1024;
+    if (wb >= (unsigned)(O / 16)) return;
+    const int o0 = wb * 16;
+    {
+      float v[36];
+      // mode 0: 16 rows (o) of 64 x 9 contiguous floats; mode 1: 64 rows (i) of 16 x 9
+      const int RL = jb.mode == 0 ? 576 : 144;
+#pragma unroll
+      for (int k = 0; k < 36; ++k) {
+        const int e = k * 256 + threadIdx.x;
+        const int r = e / RL, c = e - r * RL;
+        v[k] = jb.mode == 0 ? jb.w[((size_t)(o0 + r) * jb.Cin) * 9 + c] : jb.w[((size_t)r * jb.Cin + o0) * 9 + c];
+      }
+#pragma unroll
+      for (int k = 0; k < 36; ++k) {
+        const int e = k * 256 + threadIdx.x;
+        const int r = e / RL, c = e - r * RL;
+        tile[r * (RL + 1) + c] = v[k];
+      }
+    }
+    __syncthreads();
+    for (int tap = 0; tap < 9; ++tap) {
+      float* dst = jb.wp + bbase + ((size_t)wb * 9 + tap) * 1024;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int x = u * 256 + threadIdx.x;
+        const int l = (x >> 2) & 63;
+        const int ol = l & 15, i = (x >> 8) * 16 + (l >> 4) * 4 + (x & 3);
+        dst[x] = jb.mode == 0 ? tile[ol * 577 + i * 9 + tap] : tile[i * 145 + ol * 9 + (8 - tap)];
+      }
+    }
+    return;
+  }
+  // other kernel sizes (9x9 through the general kernels): element-wise gather, 32-bit index arithmetic, the part of the index above
+  // bit 10 decoded once per workgroup
+  const unsigned base = wl * 1024;
+  const unsigned top = base >> 11;                        // uniform (no band section for these sizes)
+  int tap = top % (unsigned)jb.KK;
+  const unsigned rr = top / (unsigned)jb.KK;
+  int a2 = (int)(rr % (unsigned)ncb) * 64, a1 = (int)(rr / (unsigned)ncb) * 32;
+  tap = __builtin_amdgcn_readfirstlane(tap); a1 = __builtin_amdgcn_readfirstlane(a1); a2 = __builtin_amdgcn_readfirstlane(a2);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const long long idx = base + u * 256 + threadIdx.x;
-    if (idx >= jb.total) break;
-    if (idx >= bbase) {   // band-kernel section
-      const long long q = idx - bbase;
-      const int l = (q >> 2) & 63, tap = (q >> 10) % 9;
-      const int o = (int)((q >> 10) / 9) * 16 + (l & 15), i = ((q >> 8) & 3) * 16 + (l >> 4) * 4 + (q & 3);
-      jb.wp[idx] = jb.mode == 0 ? jb.w[((size_t)o * jb.Cin + i) * jb.KK + tap]
-                                : jb.w[((size_t)i * jb.Cin + o) * jb.KK + (jb.KK - 1 - tap)];
-      continue;
-    }
+    const unsigned idx = base + u * 256 + threadIdx.x;
+    if (idx >= total) break;
     const int j = idx & 3, l = (idx >> 2) & 63, ks = (idx >> 8) & 7;
-    long long rest = idx >> 11;
-    const int tap = rest % jb.KK;
-    rest /= jb.KK;
-    const int cbk = rest % ncb;
-    const int of = rest / ncb;
-    const int o = of * 32 + (l & 31), i = cbk * 64 + ks * 8 + (l >> 5) * 4 + j;
+    const int o = a1 + (l & 31), i = a2 + ks * 8 + (l >> 5) * 4 + j;
     float v = 0.f;
-    if (of < (O + 31) / 32 && o < O && i < I) {
+    if (a1 < ((O + 31) / 32) * 32 && o < O && i < I) {
       if (jb.mode == 0)
         v = jb.w[((size_t)o * jb.Cin + i) * jb.KK + tap];
       else
@@ -819,7 +905,7 @@ SST_API int sst_conv_pack(const float* w, float* wp, int Cout, int Cin, int ksiz
 // mode 0 / 1: forward / data-gradient layout of a k x k conv; 2 / 3: sst_conv9_c3_pack mode 0 / 1; 4: sst_conv9_to3_pack;
 // 5: clear `total` 32-bit words at wp (w unused); 6: add Cout to `total` int64 words at wp (w unused)
 SST_API int sst_conv_pack_multi(const void* jobs, int njobs, int total_blocks, void* stream) {
-  SST_REQUIRE(jobs && njobs > 0 && total_blocks > 0, "sst_conv_pack_multi: bad argument");
+  SST_REQUIRE(jobs && njobs > 0 && njobs <= PM_MAXJOBS && total_blocks > 0, "sst_conv_pack_multi: bad argument (at most %d jobs)", PM_MAXJOBS);
   static_assert(sizeof(PackJob) == 48, "PackJob layout");
   pack_multi_kernel<<<total_blocks, 256, 0, sst_stream(stream)>>>(reinterpret_cast<const PackJob*>(jobs), njobs);
   SST_LAUNCH_CHECK("pack_multi_kernel");

@@ -703,6 +703,7 @@ class PackPlan:
             else:
                 o, i = (cin, cout) if m else (cout, cin)
                 n = _abi.lib().sst_conv_packed_floats(o, i, k)
+            assert n < 2 ** 31                                  # the pack kernel's index arithmetic is 32-bit
             wp = torch.empty(n, device=dev, dtype=torch.float32)
             self.out.append(wp)
             rows.append([w.data_ptr(), wp.data_ptr(), cout | (cin << 32), (k * k) | (int(m) << 32), n, blk])
