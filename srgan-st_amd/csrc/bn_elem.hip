@@ -7,6 +7,7 @@
 //   residual adds                       model.py:146,183
 // All reductions are two-stage with a fixed order (no atomics): bit-reproducible.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -549,16 +550,16 @@ inline int grid_for(int64_t work_items) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
+SST_API int sst_bn_finalize_grp(const float* stats, const float* cnt, int ntiles, int C, int groups, const float* gamma,
+                                const float* beta, float* run_mean, float* run_var, float* mean, float* rstd, float* scale,
+                                float* shift, float eps, float momentum, void* stream);
 SST_API int sst_bn_finalize(const float* stats, const float* cnt, int ntiles, int C, const float* gamma, const float* beta,
                             float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
                             float eps, float momentum, void* stream) {
   SST_REQUIRE(stats && cnt && gamma && beta && mean && rstd && scale && shift && ntiles > 0 && C > 0,
               "sst_bn_finalize: bad argument");
   SST_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "sst_bn_finalize: running stats must come together");
-  bn_finalize_kernel<<<C, NT, 0, sst_stream(stream)>>>(stats, cnt, ntiles, C, gamma, beta, run_mean, run_var, mean, rstd,
-                                                        scale, shift, eps, momentum, 1);
-  SST_LAUNCH_CHECK("bn_finalize_kernel");
-  return SST_OK;
+  return sst_bn_finalize_grp(stats, cnt, ntiles, C, 1, gamma, beta, run_mean, run_var, mean, rstd, scale, shift, eps, momentum, stream);
 }
 
 // The same for `groups` passes batched as one tall image: stats / cnt hold ntiles tiles = groups equal consecutive ranges; mean / rstd /
@@ -570,6 +571,10 @@ SST_API int sst_bn_finalize_grp(const float* stats, const float* cnt, int ntiles
   SST_REQUIRE(stats && cnt && gamma && beta && mean && rstd && scale && shift && ntiles > 0 && C > 0 && groups > 0 && ntiles % groups == 0,
               "sst_bn_finalize_grp: bad argument (ntiles=%d groups=%d)", ntiles, groups);
   SST_REQUIRE((run_mean == nullptr) == (run_var == nullptr), "sst_bn_finalize_grp: running stats must come together");
+  // (A 16-channels-per-workgroup form of this kernel - 1,024 threads, coalesced 64-B reads - measured SLOWER inside the step, 10.0 vs
+  // 6.8 us per launch, and taught something else on the way: its first version spilled registers to scratch memory and then returned
+  // wrong, run-to-run different statistics inside the two-branch hipGraph while being exact in eager launches: DESIGN.md section 5,
+  // tests/test_abi_symbols.py.)
   bn_finalize_kernel<<<C, NT, 0, sst_stream(stream)>>>(stats, cnt, ntiles / groups, C, gamma, beta, run_mean, run_var, mean, rstd,
                                                         scale, shift, eps, momentum, groups);
   SST_LAUNCH_CHECK("bn_finalize_kernel");

@@ -222,8 +222,11 @@ __global__ __launch_bounds__(CONV_NT, 4) void conv_wgrad_kernel(WgradArgs a, WgJ
 // at the end (same slab layout, same reduce kernel).
 constexpr int WB_XS = 10, WB_DS = 3;      // max register slots (16 B each) per thread for the X patch / dY tile of one band
 
+// (XS = 10 under the 256-VGPR cap of two waves per SIMD spilled 11 registers to scratch memory; a kernel with a private segment is
+// not safe inside the two-branch hipGraph of the iteration - see DESIGN.md section 5, tests/test_abi_symbols.py - so that instance gets the
+// whole register file: one workgroup per CU, which its 80 KB of LDS nearly forced anyway)
 template <int XS>
-__global__ __launch_bounds__(CONV_NT, 2) void conv_wgrad_band_kernel(WgradArgs a, WgJobTab tab) {
+__global__ __launch_bounds__(CONV_NT, (XS > 7 ? 1 : 2)) void conv_wgrad_band_kernel(WgradArgs a, WgJobTab tab) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   int chunk = blockIdx.x;
   if (a.grouped) {

@@ -42,3 +42,41 @@ def test_library_identity_and_error_channel():
     assert lib.sst_conv_packed_floats(64, 64, 3) == 2 * 1 * 9 * 8 * 256 + 2048 + 64 * 64 * 9   # + band-kernel copy
     assert lib.sst_conv_packed_floats(128, 128, 3) == 4 * 2 * 9 * 8 * 256 + 2048
     assert lib.sst_conv_stat_tiles(16, 24, 24, 64, 64, 3, 1) == 192 and lib.sst_conv_stat_tiles(16, 24, 24, 64, 64, 3, 2) == 96
+
+
+# Kernels allowed to use scratch (private segment) memory: none that can run inside the training iteration's hipGraph.  A kernel with
+# spilled registers returned wrong, run-to-run different results next to a concurrently running branch of the two-branch graph on
+# ROCm 7.2 (an experimental BatchNorm finalize with 38 spilled registers) while being exact in eager launches - so spills are a
+# correctness matter here, not a performance note.  The one exception runs eagerly only, on its own: the best-buddy matcher of the
+# optional patch losses (loss.py:86).
+SCRATCH_ALLOWED = ("bb_match_kernel",)
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
+    import shutil
+    import subprocess
+    import pytest
+    from srganst import _abi
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf = os.path.join(llvm, "llvm-objdump"), os.path.join(llvm, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm LLVM binutils not found")
+    so = shutil.copy(_abi.LIB_PATH, tmp_path / "libsrganst.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)     # extracts the code objects
+    objs = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert objs, "no gfx950 code object found in libsrganst.so"
+    seen, bad = 0, []
+    for f in objs:
+        notes = subprocess.run([readelf, "--notes", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split(":", 1)[1].strip()
+            elif line.startswith(".private_segment_fixed_size:") and name is not None:
+                seen += 1
+                if int(line.split(":", 1)[1]) > 0 and not any(a in name for a in SCRATCH_ALLOWED):
+                    bad.append((name, int(line.split(":", 1)[1])))
+                name = None
+    assert seen > 100, f"only {seen} kernels found"
+    assert not bad, f"kernels with scratch memory (spilled registers): {bad}"

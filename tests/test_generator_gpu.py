@@ -182,8 +182,8 @@ def test_accumulator_mode_equals_partial_tile_mode(monkeypatch):
     for (sr_a, gr_a, bn_a), (sr_b, gr_b, bn_b) in zip(res["1"], res["0"]):
         assert rel_err(sr_a, sr_b) < 1e-5
         for n in gr_a:
-            tol = 1e-3 if gr_a[n].numel() == 1 else 5e-4      # scalar slope gradients are cancelling sums; the rest: two fp32
-            # orderings of the statistics, seen through 3 blocks' backward (2.4e-4 on conv1.0.weight, the longest path)
+            tol = 1e-3      # two fp32 orderings of the statistics seen through 3 blocks' backward: 2.4e-4 .. 5.0e-4 on conv1.0.weight
+            # (the longest path) depending on the finalize kernel's summation order; scalar slope gradients are cancelling sums
             assert rel_err(gr_a[n], gr_b[n]) < tol, n
         for k in bn_a:
             assert torch.allclose(bn_a[k], bn_b[k], rtol=1e-5, atol=1e-7), k
